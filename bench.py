@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: fused FLE int32 (w=32) decode + LT predicate @10% selectivity.
+
+One "step" = one pass of the hot path (ips_fle_scan: predicate on the encoded bit-planes ->
+selection bitmap, selected rows decoded and written per 2048-row batch) over one batch of
+synthetic column chunks already resident in HBM; with N > 1 each rank scans its own row stripe and
+the step ends with an RCCL all-gather of the per-stripe bitmaps over xGMI.
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the byte accounting.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+METRIC = "decoded+filtered rows/sec and HBM GB/s vs roofline, int32 FLE @10% sel"
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1 << 28,
+                    help="rows per GPU per step (256 column chunks of 2^20 rows)")
+    ap.add_argument("--bw", type=int, default=32)
+    ap.add_argument("--sel", type=float, default=0.10)
+    ap.add_argument("--cpu-rows", type=int, default=1 << 26, help="cpu_baseline sample rows")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N>1 with "
+                  "torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # nccl IS RCCL on ROCm
+
+    ips = entry.load_package()
+    capi = ips.capi
+    capi.lib()  # fail loudly if the HIP library is missing: there is no fallback
+    n, bw = args.rows, args.bw
+    c = ips.synth.lt_constant(bw, args.sel)
+    seed = ips.synth.SEED_HEADLINE + rank * n  # rank r holds rows [r*n, (r+1)*n) of the column
+
+    # ---- synthetic column chunk(s), generated and FLE-encoded on the GPU ----------------------
+    vals = capi.synth_u32(seed, n, bw, device=dev)
+    enc = capi.fle_encode(vals, bw)
+    torch.cuda.synchronize()
+    # spot parity vs the oracle on the first 2^20 rows (config 1) before timing anything
+    check = None
+    O = None
+    if rank == 0:
+        O = entry.load_oracle()
+        n1 = min(n, 1 << 20)
+        host_vals = ips.synth.column_u32(seed, n1, bw)
+        assert np.array_equal(vals[:n1].cpu().numpy().view(np.uint32), host_vals)
+        enc1 = O.fle_encode(host_vals, bw)
+        assert np.array_equal(enc[:len(enc1)].cpu().numpy().view(np.uint64), enc1)
+    del vals
+    torch.cuda.empty_cache()
+
+    outputs = capi.alloc_scan_outputs(n, dev)
+    words = (n + 63) // 64
+    full_bitmap = torch.empty(words * world, dtype=torch.int64, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream()
+
+    def step():
+        bitmap, bvals, counts = capi.fle_scan(enc, n, bw, capi.OP_LT, c, outputs=outputs)
+        if world > 1:
+            dist.all_gather_into_tensor(full_bitmap, bitmap)
+        return bitmap, bvals, counts
+
+    for _ in range(args.warmup):
+        bitmap, bvals, counts = step()
+    torch.cuda.synchronize()
+    n_sel = int(counts.to(torch.int64).sum().item())
+    if rank == 0:
+        n1 = min(n, 1 << 20)
+        bm_ref = O.fle_pred(enc1, n1, bw, O.OP_LT, c)
+        got = bitmap[:len(bm_ref)].cpu().numpy().view(np.uint64)
+        ok_bm = bool(np.array_equal(got, bm_ref))
+        sel_ref = O.fle_select(enc1, n1, bw, bm_ref)
+        nb1 = capi.n_batches(n1)
+        cnt_h = counts[:nb1].cpu().numpy()
+        bv_h = bvals[:nb1 * capi.BATCH_ROWS].cpu().numpy().view(np.uint32)
+        got_sel = np.concatenate([bv_h[b * 2048: b * 2048 + cnt_h[b]] for b in range(nb1)])
+        ok_sel = bool(np.array_equal(got_sel, sel_ref))
+        ok_cnt = capi.bitmap_count(bitmap, n) == n_sel
+        check = {"first_2^20_rows_bitmap_bit_exact": ok_bm, "selected_values_bit_exact": ok_sel,
+                 "popcount_equals_batch_counts": bool(ok_cnt)}
+        assert ok_bm and ok_sel and ok_cnt, check
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides ------------------
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        capi.fle_scan(enc, n, bw, capi.OP_LT, c, outputs=outputs)
+        ev[i][1].record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(full_bitmap, outputs[0][:words])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+
+    if world > 1:  # bit-identity of the gathered bitmap: slice r equals rank r's local bitmap
+        mine = full_bitmap[rank * words:(rank + 1) * words]
+        assert torch.equal(mine, outputs[0][:words])
+
+    # ---- 1M-row single-chunk latency (config 1/2 literally: launch-bound) ---------------------
+    n1 = 1 << 20
+    lat_us = None
+    if n >= n1:
+        out1 = capi.alloc_scan_outputs(n1, dev)
+        for _ in range(5):
+            capi.fle_scan(enc, n1, bw, capi.OP_LT, c, outputs=out1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(reps):
+            capi.fle_scan(enc, n1, bw, capi.OP_LT, c, outputs=out1)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        lat_us = e0.elapsed_time(e1) * 1000.0 / reps
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (fle_scan_kernel<32, predicate>) --------------------
+    blocks = (n + 63) // 64
+    algo_bytes = 8 * bw * blocks + 8 * blocks + 4 * n_sel  # SURVEY 8(d) "F"
+    achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("rows") == n and tj.get("bit_width") == bw:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": f"ips::fle_scan_kernel<{bw},0,0>",
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "kernel_ms_avg": round(kern_avg_ms, 4), "kernel_ms_min": round(kern_ms[0], 4)}
+
+    # ---- CPU baseline: the oracle port on this box's host cores, bounded sample ---------------
+    cpu = None
+    if not args.no_cpu and world == 1:
+        nc = min(args.cpu_rows, n)
+        enc_h = enc[: (nc // 64) * bw].cpu().numpy().view(np.uint64)
+        threads = O.hw_threads()
+        best = {}
+        for mode in (0, 1):
+            O.bench_fused(enc_h, nc, bw, O.OP_LT, c, threads, mode)  # warm-up
+            ts = []
+            for _ in range(5):
+                t = time.perf_counter()
+                cnt, _, _ = O.bench_fused(enc_h, nc, bw, O.OP_LT, c, threads, mode)
+                ts.append(time.perf_counter() - t)
+            best[mode] = nc / min(ts)
+        cpu = {"value": round(max(best.values()), 1), "unit": "rows/s", "cores": threads,
+               "kind": "port",
+               "sample": (f"first {nc} rows of the same column, same LT constant; oracle C port "
+                          f"(scalar uint64 predicate as fle-encoding.h:8012-8066 + SWAR block unpack"
+                          f"{', avx2 clones' if O.has_avx2() else ''}), one stripe per thread, best of 5; "
+                          f"one call per stripe {best[0]:.3e} rows/s, reference-shaped 1024-row "
+                          f"batches {best[1]:.3e} rows/s"),
+               "single_thread_note": "the reference itself is unbuildable in this image (Boost/Impala headers absent)"}
+
+    total_rows = n * world
+    out = {
+        "metric": METRIC, "value": round(total_rows * args.steps / elapsed, 1), "unit": "rows/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {
+            "workload": ("BASELINE configs[1]: int32 FLE (w=32) column, single LT predicate @10% "
+                         "selectivity, fused decode+LT kernel -> bitmap + selected values; "
+                         f"{n >> 20} column chunks of 2^20 rows per GPU resident in HBM per step "
+                         "(the 2^20-row single-chunk launch is latency-bound, see extra.latency)"),
+            "rows_per_gpu": n, "bit_width": bw, "predicate": f"LT {c}",
+            "selectivity": round(n_sel / n, 5), "batch_rows": capi.BATCH_ROWS,
+            "parallelism": (f"{world} row stripes, RCCL all-gather of bitmap words per step"
+                            if world > 1 else "single GPU"),
+        },
+        "roofline": roofline, "cpu_baseline": cpu,
+        "extra": {"check": check, "selected_rows": n_sel,
+                  "latency": {"rows": n1, "us_per_launch_back_to_back": lat_us and round(lat_us, 2)},
+                  "device": capi.device_info()[0]},
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

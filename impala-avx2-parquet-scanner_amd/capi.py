@@ -1,0 +1,373 @@
+"""ctypes binding of libips_hip.so (include/ips.h) for tests and bench.py.
+
+torch is used only as plumbing: device buffers, streams, torch.distributed.  Every function here
+is a thin call through the C-ABI; there is no Python or CPU fallback -- a missing or failing
+library raises.
+
+torch must be imported before the library is loaded so that both share one HIP runtime.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch  # noqa: F401  (load torch's HIP runtime first)
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "libips_hip.so")
+
+OP_EQ, OP_LT, OP_LE, OP_GT, OP_GE, OP_IN = range(6)
+T_INT8, T_INT16, T_INT32, T_INT64, T_FLOAT, T_DOUBLE = range(6)
+SEM_REFERENCE, SEM_SQL = 0, 1
+XL_ALL_FALSE, XL_ALL_TRUE, XL_FLE = 0, 1, 2
+NODE_LEAF, NODE_AND, NODE_OR = 0, 1, 2
+COL_FLE, COL_PLAIN = 0, 1
+BATCH_ROWS = 2048
+MAX_IN_LIST = 256
+
+NP_TYPES = {T_INT8: np.int8, T_INT16: np.int16, T_INT32: np.int32, T_INT64: np.int64,
+            T_FLOAT: np.float32, T_DOUBLE: np.float64}
+TORCH_SLOT = {T_INT8: torch.int32, T_INT16: torch.int32, T_INT32: torch.int32,
+              T_INT64: torch.int64, T_FLOAT: torch.float32, T_DOUBLE: torch.float64}
+
+# every symbol include/ips.h declares (tests/test_abi.py checks the header against this list and
+# the built library against both)
+SYMBOLS = [
+    "ips_version", "ips_last_error", "ips_device_count", "ips_set_device", "ips_device_info",
+    "ips_malloc", "ips_free", "ips_memcpy_h2d", "ips_memcpy_d2h", "ips_memset",
+    "ips_stream_create", "ips_stream_destroy", "ips_stream_synchronize",
+    "ips_fle_encoded_bytes", "ips_fle_encode", "ips_fle_decode", "ips_fle_pred", "ips_fle_scan",
+    "ips_fle_select", "ips_batches_workspace_bytes", "ips_batches_compact",
+    "ips_dict_open", "ips_dict_close", "ips_dict_num_entries", "ips_dict_bit_width",
+    "ips_dict_translate", "ips_dict_pred", "ips_dict_decode", "ips_dict_scan",
+    "ips_plain_stride", "ips_plain_pred",
+    "ips_bitmap_and", "ips_bitmap_or", "ips_bitmap_fill", "ips_bitmap_count",
+    "ips_expand_workspace_bytes", "ips_bitmap_expand",
+    "ips_eval_program", "ips_synth_splitmix_u32",
+]
+
+
+class IpsError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"ips status {status}: {msg}")
+        self.status = status
+
+
+class Column(C.Structure):
+    _fields_ = [("encoding", C.c_int32), ("bit_width", C.c_int32), ("type", C.c_int32),
+                ("reserved", C.c_int32), ("d_data", C.c_void_p)]
+
+
+class Node(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("column", C.c_int32), ("op", C.c_int32),
+                ("n_consts", C.c_int32), ("consts", C.c_uint64 * 16)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libips_hip.so; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.ips_last_error.restype = C.c_char_p
+        L.ips_fle_encoded_bytes.restype = C.c_int64
+        L.ips_fle_encoded_bytes.argtypes = [C.c_int64, C.c_int]
+        L.ips_dict_num_entries.restype = C.c_int64
+        L.ips_dict_num_entries.argtypes = [C.c_void_p]
+        L.ips_dict_bit_width.argtypes = [C.c_int64]
+        for name in ("ips_batches_workspace_bytes", "ips_expand_workspace_bytes"):
+            getattr(L, name).restype = C.c_size_t
+            getattr(L, name).argtypes = [C.c_int64]
+        _lib = L
+    return _lib
+
+
+def _ck(status):
+    if status != 0:
+        raise IpsError(status, lib().ips_last_error().decode())
+
+
+def _ptr(t):
+    """device pointer of a torch tensor (or pass through an int / None)."""
+    if t is None:
+        return C.c_void_p(0)
+    if isinstance(t, torch.Tensor):
+        assert t.is_contiguous()
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(int(t))
+
+
+def _stream(stream=None):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return C.c_void_p(stream.cuda_stream)
+
+
+def _words(n_rows):
+    return (n_rows + 63) // 64
+
+
+def n_batches(n_rows):
+    return (n_rows + BATCH_ROWS - 1) // BATCH_ROWS
+
+
+def version():
+    return int(lib().ips_version())
+
+
+def device_info():
+    name = C.create_string_buffer(128)
+    cus = C.c_int(0)
+    hbm = C.c_int64(0)
+    _ck(lib().ips_device_info(name, 128, C.byref(cus), C.byref(hbm)))
+    return name.value.decode(), cus.value, hbm.value
+
+
+def fle_encoded_bytes(n_rows, bw):
+    return int(lib().ips_fle_encoded_bytes(n_rows, bw))
+
+
+def _consts(values):
+    v = np.ascontiguousarray(np.atleast_1d(values), dtype=np.uint64)
+    return v, v.ctypes.data_as(C.POINTER(C.c_uint64)), len(v)
+
+
+# ---- FLE ------------------------------------------------------------------------------------
+def fle_encode(values, bw, out=None, stream=None):
+    """values: cuda tensor of uint8 / int16 / int32 (unsigned meaning) -> int64 words."""
+    in_width = values.element_size()
+    n = values.numel()
+    if out is None:
+        out = torch.empty(max(fle_encoded_bytes(n, bw) // 8, 2), dtype=torch.int64,
+                          device=values.device)
+    _ck(lib().ips_fle_encode(_ptr(values), in_width, C.c_int64(n), bw, _ptr(out), _stream(stream)))
+    return out[:fle_encoded_bytes(n, bw) // 8]
+
+
+def fle_decode(enc, n_rows, bw, out_width=4, out=None, stream=None):
+    dt = {1: torch.uint8, 2: torch.int16, 4: torch.int32}[out_width]
+    if out is None:
+        out = torch.empty(max(n_rows, 16), dtype=dt, device=enc.device)
+    _ck(lib().ips_fle_decode(_ptr(enc), C.c_int64(n_rows), bw, _ptr(out), out_width,
+                             _stream(stream)))
+    return out[:n_rows]
+
+
+def fle_pred(enc, n_rows, bw, op, values, bitmap=None, stream=None):
+    keep, p, k = _consts(values)
+    if bitmap is None:
+        bitmap = torch.empty(max(_words(n_rows), 2), dtype=torch.int64, device=enc.device)
+    _ck(lib().ips_fle_pred(_ptr(enc), C.c_int64(n_rows), bw, op, p, k, _ptr(bitmap),
+                           _stream(stream)))
+    return bitmap[:_words(n_rows)]
+
+
+def alloc_scan_outputs(n_rows, device, value_dtype=torch.int32):
+    nb = max(n_batches(n_rows), 1)
+    bitmap = torch.empty(max(_words(n_rows), 2), dtype=torch.int64, device=device)
+    values = torch.empty(nb * BATCH_ROWS, dtype=value_dtype, device=device)
+    counts = torch.empty(nb, dtype=torch.int32, device=device)
+    return bitmap, values, counts
+
+
+def fle_scan(enc, n_rows, bw, op, values, outputs=None, stream=None):
+    """-> (bitmap words, batch values, batch counts)"""
+    keep, p, k = _consts(values)
+    bitmap, bvals, counts = outputs or alloc_scan_outputs(n_rows, enc.device)
+    _ck(lib().ips_fle_scan(_ptr(enc), C.c_int64(n_rows), bw, op, p, k, _ptr(bitmap), _ptr(bvals),
+                           _ptr(counts), _stream(stream)))
+    return bitmap[:_words(n_rows)], bvals, counts[:n_batches(n_rows)]
+
+
+def fle_select(enc, n_rows, bw, bitmap, outputs=None, stream=None):
+    _, bvals, counts = outputs or alloc_scan_outputs(n_rows, enc.device)
+    _ck(lib().ips_fle_select(_ptr(enc), C.c_int64(n_rows), bw, _ptr(bitmap), _ptr(bvals),
+                             _ptr(counts), _stream(stream)))
+    return bvals, counts[:n_batches(n_rows)]
+
+
+def batches_compact(bvals, counts, n_rows, stream=None):
+    """-> dense tensor of the selected values in row order."""
+    width = bvals.element_size()
+    ws = torch.empty(max(int(lib().ips_batches_workspace_bytes(n_rows)), 16), dtype=torch.uint8,
+                     device=bvals.device)
+    dense = torch.empty(max(n_rows, 16), dtype=bvals.dtype, device=bvals.device)
+    total = torch.zeros(1, dtype=torch.int64, device=bvals.device)
+    _ck(lib().ips_batches_compact(_ptr(bvals), _ptr(counts), C.c_int64(n_rows), width,
+                                  _ptr(dense), _ptr(total), _ptr(ws), _stream(stream)))
+    return dense[:int(total.item())]
+
+
+# ---- dictionary -----------------------------------------------------------------------------
+class Dict:
+    """ips_dict handle (DictDecoder<T>, dict-encoding.h:202-232)."""
+
+    def __init__(self, dict_page, type_):
+        page = np.ascontiguousarray(dict_page, dtype=np.uint8)
+        self.type = type_
+        self.h = C.c_void_p(0)
+        _ck(lib().ips_dict_open(page.ctypes.data_as(C.c_void_p), C.c_int64(len(page)), type_,
+                                C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().ips_dict_close(self.h)
+            self.h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_entries(self):
+        return int(lib().ips_dict_num_entries(self.h))
+
+    def _lits(self, literals):
+        v = np.ascontiguousarray(np.atleast_1d(literals), dtype=NP_TYPES[self.type])
+        return v, v.ctypes.data_as(C.c_void_p), len(v)
+
+    def translate(self, op, literals):
+        keep, p, k = self._lits(literals)
+        kind, fle_op, n_codes = C.c_int(0), C.c_int(0), C.c_int(0)
+        codes = (C.c_uint64 * max(k, 1))()
+        _ck(lib().ips_dict_translate(self.h, op, p, k, C.byref(kind), C.byref(fle_op), codes,
+                                     C.byref(n_codes)))
+        return kind.value, fle_op.value, [int(codes[i]) for i in range(n_codes.value)]
+
+    def pred(self, codes_enc, n_rows, bw, op, literals, bitmap=None, stream=None):
+        keep, p, k = self._lits(literals)
+        if bitmap is None:
+            bitmap = torch.empty(max(_words(n_rows), 2), dtype=torch.int64, device=codes_enc.device)
+        _ck(lib().ips_dict_pred(self.h, _ptr(codes_enc), C.c_int64(n_rows), bw, op, p, k,
+                                _ptr(bitmap), _stream(stream)))
+        return bitmap[:_words(n_rows)]
+
+    def decode(self, codes_enc, n_rows, bw, stream=None):
+        out = torch.empty(max(n_rows, 16), dtype=TORCH_SLOT[self.type], device=codes_enc.device)
+        bad = torch.zeros(1, dtype=torch.int32, device=codes_enc.device)
+        _ck(lib().ips_dict_decode(self.h, _ptr(codes_enc), C.c_int64(n_rows), bw, _ptr(out),
+                                  _ptr(bad), _stream(stream)))
+        return out[:n_rows], bad
+
+    def scan(self, codes_enc, n_rows, bw, op, literals, stream=None):
+        keep, p, k = self._lits(literals)
+        bitmap, bvals, counts = alloc_scan_outputs(n_rows, codes_enc.device, TORCH_SLOT[self.type])
+        _ck(lib().ips_dict_scan(self.h, _ptr(codes_enc), C.c_int64(n_rows), bw, op, p, k,
+                                _ptr(bitmap), _ptr(bvals), _ptr(counts), _stream(stream)))
+        return bitmap[:_words(n_rows)], bvals, counts[:n_batches(n_rows)]
+
+
+def dict_bit_width(num_entries):
+    return int(lib().ips_dict_bit_width(num_entries))
+
+
+# ---- PLAIN ----------------------------------------------------------------------------------
+def plain_pred(page, n_rows, type_, op, literals, semantics=SEM_SQL, bitmap=None, stream=None):
+    v = np.ascontiguousarray(np.atleast_1d(literals), dtype=NP_TYPES[type_])
+    if bitmap is None:
+        bitmap = torch.empty(max(_words(n_rows), 2), dtype=torch.int64, device=page.device)
+    _ck(lib().ips_plain_pred(_ptr(page), C.c_int64(n_rows), type_, op,
+                             v.ctypes.data_as(C.c_void_p), len(v), semantics, _ptr(bitmap),
+                             _stream(stream)))
+    return bitmap[:_words(n_rows)]
+
+
+# ---- bitmap algebra -------------------------------------------------------------------------
+def bitmap_and(a, b, n_rows, stream=None):
+    _ck(lib().ips_bitmap_and(_ptr(a), _ptr(b), C.c_int64(n_rows), _stream(stream)))
+    return a
+
+
+def bitmap_or(a, b, n_rows, stream=None):
+    _ck(lib().ips_bitmap_or(_ptr(a), _ptr(b), C.c_int64(n_rows), _stream(stream)))
+    return a
+
+
+def bitmap_fill(a, n_rows, value, stream=None):
+    _ck(lib().ips_bitmap_fill(_ptr(a), C.c_int64(n_rows), int(value), _stream(stream)))
+    return a
+
+
+def bitmap_count(a, n_rows, stream=None):
+    cnt = torch.zeros(1, dtype=torch.int64, device=a.device)
+    _ck(lib().ips_bitmap_count(_ptr(a), C.c_int64(n_rows), _ptr(cnt), _stream(stream)))
+    return int(cnt.item())
+
+
+def bitmap_expand(root, sub, n_rows, stream=None):
+    ws = torch.empty(max(int(lib().ips_expand_workspace_bytes(n_rows)), 16), dtype=torch.uint8,
+                     device=root.device)
+    out = torch.empty(max(_words(n_rows), 2), dtype=torch.int64, device=root.device)
+    _ck(lib().ips_bitmap_expand(_ptr(root), _ptr(sub), C.c_int64(n_rows), _ptr(out), _ptr(ws),
+                                _stream(stream)))
+    return out[:_words(n_rows)]
+
+
+# ---- fused predicate program ----------------------------------------------------------------
+def leaf(column, op, consts):
+    n = Node()
+    n.kind, n.column, n.op = NODE_LEAF, column, op
+    cs = np.atleast_1d(consts)
+    n.n_consts = len(cs)
+    for i, c in enumerate(cs):
+        n.consts[i] = int(c)
+    return n
+
+
+def plain_leaf(column, op, literals, type_):
+    """PLAIN leaves carry the literal's bit pattern in the 64-bit constant slots."""
+    v = np.ascontiguousarray(np.atleast_1d(literals), dtype=NP_TYPES[type_])
+    raw = np.zeros(len(v), dtype=np.uint64)
+    raw.view(np.uint8).reshape(len(v), 8)[:, :v.itemsize] = v.view(np.uint8).reshape(len(v), -1)
+    return leaf(column, op, raw)
+
+
+def and_node():
+    n = Node()
+    n.kind = NODE_AND
+    return n
+
+
+def or_node():
+    n = Node()
+    n.kind = NODE_OR
+    return n
+
+
+def fle_column(enc, bw):
+    c = Column()
+    c.encoding, c.bit_width, c.type, c.d_data = COL_FLE, bw, 0, enc.data_ptr()
+    return c
+
+
+def plain_column(page, type_):
+    c = Column()
+    c.encoding, c.bit_width, c.type, c.d_data = COL_PLAIN, 0, type_, page.data_ptr()
+    return c
+
+
+def eval_program(nodes, cols, n_rows, bitmap=None, device=None, stream=None):
+    arr_n = (Node * len(nodes))(*nodes)
+    arr_c = (Column * len(cols))(*cols)
+    if bitmap is None:
+        bitmap = torch.empty(max(_words(n_rows), 2), dtype=torch.int64,
+                             device=device or torch.device("cuda"))
+    _ck(lib().ips_eval_program(arr_n, len(nodes), arr_c, len(cols), C.c_int64(n_rows),
+                               _ptr(bitmap), _stream(stream)))
+    return bitmap[:_words(n_rows)]
+
+
+# ---- synthetic ------------------------------------------------------------------------------
+def synth_u32(seed, n, bit_width, device=None, stream=None):
+    out = torch.empty(max(n, 16), dtype=torch.int32, device=device or torch.device("cuda"))
+    mask = (1 << bit_width) - 1
+    _ck(lib().ips_synth_splitmix_u32(C.c_uint64(seed), C.c_int64(n), C.c_uint32(mask), _ptr(out),
+                                     _stream(stream)))
+    return out[:n]

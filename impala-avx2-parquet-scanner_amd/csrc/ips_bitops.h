@@ -1,0 +1,132 @@
+// ips_bitops.h -- per-lane bit arithmetic of the FLE kernels.
+//
+// One lane owns one HALF-BLOCK: 32 consecutive rows of a 64-row FLE block, i.e. one 32-bit half of
+// each of the block's W plane words (fle-encoding.h:8338-8340: word i holds bit i of the 64
+// values, value k at bit 63-k, so rows 0..31 live in the high dword and rows 32..63 in the low
+// dword, both MSB-first).  Everything here is straight-line 32-bit integer code with compile-time
+// trip counts so that hipcc keeps planes and values in VGPRs.
+//
+// The functions are __host__ __device__ so the exact code the kernels run can be unit-tested on
+// the CPU build (tests/host_bitops_test.cpp); the product path never runs them on the host.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define IPS_HD __host__ __device__ __forceinline__
+#else
+#define IPS_HD inline
+#endif
+
+namespace ips {
+
+// Comparison state of one half-block against a constant, MSB -> LSB (the Mlt/Meq recurrence of
+// fle-encoding.h:8039-8042; Mgt of :8151-8154 is ~(Mlt|Meq) and is never materialised).
+struct CmpState {
+  uint32_t lt;
+  uint32_t eq;
+};
+
+// One plane step.  x = this lane's 32 bits of plane i, c = all-ones if bit i of the constant is
+// set else zero (wave-uniform).
+IPS_HD void cmp_step(CmpState& s, uint32_t x, uint32_t c) {
+  uint32_t t = x ^ c;          // bit differs from the constant
+  s.lt |= s.eq & c & t;        // constant has 1, value has 0, equal so far
+  s.eq &= ~t;
+}
+
+// Final selection for Eq/Lt/Le/Gt/Ge from (lt, eq): sel_lt/sel_eq pick the terms, inv flips.
+//   EQ: eq            LT: lt            LE: lt|eq
+//   GT: ~(lt|eq)      GE: ~lt
+IPS_HD uint32_t cmp_select(const CmpState& s, int op) {
+  switch (op) {
+    case 0: return s.eq;
+    case 1: return s.lt;
+    case 2: return s.lt | s.eq;
+    case 3: return ~(s.lt | s.eq);
+    default: return ~s.lt;
+  }
+}
+
+IPS_HD uint32_t bitrev32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bitreverse32(v);
+#else
+  v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+  v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+  v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+  v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+  return (v >> 16) | (v << 16);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// 32x32 bit-matrix transpose, in registers.
+//
+// In:  a[i] = this lane's 32 bits of plane i (i < W; rows i >= W are zero and are folded away by
+//      the compiler because W and all indices are compile-time constants).
+// Out: a[r] bit i = (input a[i]) bit r, i.e. a[r] is the W-bit value whose plane bits sit at bit
+//      position r.  Row j of the half-block sits at bit 31-j, so value(row j) = a[31 - j].
+//
+// Five butterfly stages; a stage with distance J exchanges, for every pair (k, k+J), the bit
+// groups selected by M: two shifts + two bit-selects (v_bfi_b32) per pair.
+// ---------------------------------------------------------------------------------------------
+template <int J, uint32_t M>
+IPS_HD void transpose_stage(uint32_t (&a)[32]) {
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    if ((k & J) == 0) {
+      uint32_t lo = a[k], hi = a[k + J];
+      a[k] = (lo & M) | ((hi << J) & ~M);
+      a[k + J] = ((lo >> J) & M) | (hi & ~M);
+    }
+  }
+}
+
+IPS_HD void transpose32(uint32_t (&a)[32]) {
+  transpose_stage<16, 0x0000FFFFu>(a);
+  transpose_stage<8, 0x00FF00FFu>(a);
+  transpose_stage<4, 0x0F0F0F0Fu>(a);
+  transpose_stage<2, 0x33333333u>(a);
+  transpose_stage<1, 0x55555555u>(a);
+}
+
+// Planes -> values for one half-block.  p[0..W) in, v[j] = value of row j (j = 0..31) out.
+template <int W>
+IPS_HD void planes_to_values(const uint32_t (&p)[W], uint32_t (&v)[32]) {
+  uint32_t a[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) a[i] = i < W ? p[i] : 0u;
+  transpose32(a);
+#pragma unroll
+  for (int j = 0; j < 32; ++j) v[j] = a[31 - j];
+}
+
+// Values -> planes (the encoder direction): v[j] = value of row j, p[i] = plane i bits.
+template <int W>
+IPS_HD void values_to_planes(const uint32_t (&v)[32], uint32_t (&p)[W]) {
+  uint32_t a[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) a[31 - j] = v[j];
+  transpose32(a);
+#pragma unroll
+  for (int i = 0; i < W; ++i) p[i] = a[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tile geometry shared by host launch code and kernels.
+// A wave works on SUB-TILES of 32 blocks = 2048 rows (IPS_BATCH_ROWS).  In LDS each block's W
+// plane words are stored with an odd word stride so that the 32 lanes of a ds_read group hit 32
+// different banks ((block*stride) mod 16 is then a bijection over 16 consecutive blocks).
+// ---------------------------------------------------------------------------------------------
+constexpr int kBlocksPerTile = 32;
+constexpr int kRowsPerTile = kBlocksPerTile * 64;  // 2048
+constexpr int kRowTileStrideDw = 36;               // 32 values + 4 dwords pad per lane (144 B)
+constexpr int kRowTileBytes = 64 * kRowTileStrideDw * 4;  // 9216
+
+constexpr int plane_stride_words(int w) { return w | 1; }
+constexpr int plane_tile_bytes(int w) { return kBlocksPerTile * plane_stride_words(w) * 8; }
+
+// dword offset of row rho (0..2047) inside the padded row tile
+IPS_HD int row_tile_dw(int rho) { return (rho >> 5) * kRowTileStrideDw + (rho & 31); }
+
+}  // namespace ips

@@ -1,0 +1,252 @@
+// ips_device.h -- device-side building blocks shared by the FLE kernels (gfx950 only).
+//
+// Execution model ("one wavefront per row-group stripe"): a wave owns whole SUB-TILES of 32 FLE
+// blocks (2048 rows = IPS_BATCH_ROWS) and never synchronises with another wave; a workgroup is
+// just 4 such waves sharing a CU.  Per sub-tile a wave
+//   1. pulls the encoded bytes HBM -> VGPR with 16-byte coalesced loads (the next sub-tile's
+//      loads are issued before the current one is consumed: register prefetch),
+//   2. scatters them into its private LDS region in a bank-conflict-free (odd stride) layout,
+//   3. re-reads them lane-per-half-block (lane l <-> block l/2, rows 32*(l&1)..+31),
+//   4. runs the predicate recurrence / the 32x32 bit transposes in registers,
+//   5. exchanges results through the same LDS region to get coalesced, row-ordered stores.
+// LDS operations of one wave execute in order, so steps 2->3 and 4->5 need only a compiler-level
+// wavefront fence, never s_barrier.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ips_bitops.h"
+
+namespace ips {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kThreads = kWave * kWavesPerBlock;
+#ifndef IPS_MIN_WAVES_PER_EU
+#define IPS_MIN_WAVES_PER_EU 3
+#endif
+
+// Predicate parameters travel in the kernarg segment: wave-uniform, read with scalar loads.
+struct PredArgs {
+  int32_t op;        // ips_op
+  int32_t n_consts;  // 1, or 1..256 for IN
+  uint32_t consts[256];
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+// wave index inside the workgroup, as a scalar (SGPR) value so that everything derived from it
+// (tile numbers, bounds, branches) stays on the scalar unit
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
+// 0 or ~0 from bit k of c (one s_bfe_i32)
+__device__ __forceinline__ uint32_t bit_mask(uint32_t c, int k) {
+  return (uint32_t)(((int32_t)(c << (31 - k))) >> 31);
+}
+
+// ---- HBM -> VGPR ---------------------------------------------------------------------------
+// A full sub-tile is 32*W words = 16*W chunks of 16 bytes; lane l takes chunks l, l+64, ...
+// MAXLOADS = ceil(16*W/64).  'total_words' bounds the encoded buffer: nothing beyond
+// ceil(n/64)*W words is ever read (the reference's unpackers over-read 32 bytes, quirk Q5).
+template <int MAXLOADS>
+__device__ __forceinline__ void tile_load(const uint64_t* __restrict__ enc, int64_t tile, int w,
+                                          int64_t total_words, int lane, u32x4 (&r)[MAXLOADS]) {
+  const int64_t w0 = tile * (int64_t)(kBlocksPerTile * w);
+  const int chunks = 16 * w;
+  const uint64_t* base = enc + w0;
+  if (w0 + kBlocksPerTile * w <= total_words) {  // wave-uniform: full tile, no per-lane bounds
+#pragma unroll
+    for (int i = 0; i < MAXLOADS; ++i) {
+      int c = i * kWave + lane;
+      if (c < chunks) r[i] = *reinterpret_cast<const u32x4*>(base + 2 * c);
+    }
+  } else {
+    const int64_t left = total_words - w0;  // words available in this (last) tile
+#pragma unroll
+    for (int i = 0; i < MAXLOADS; ++i) {
+      int c = i * kWave + lane;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (c < chunks) {
+        if (2 * c + 1 < left) {
+          v = *reinterpret_cast<const u32x4*>(base + 2 * c);
+        } else if (2 * c < left) {
+          u32x2 h = *reinterpret_cast<const u32x2*>(base + 2 * c);
+          v.x = h.x; v.y = h.y;
+        }
+      }
+      r[i] = v;
+    }
+  }
+}
+
+// ---- VGPR -> LDS (odd word stride per block) ------------------------------------------------
+template <int MAXLOADS>
+__device__ __forceinline__ void tile_to_lds(uint32_t* lds32, int w, int lane,
+                                            const u32x4 (&r)[MAXLOADS]) {
+  const int chunks = 16 * w;
+  const int stride = w | 1;
+  if (w & 1) {  // stride == w: the LDS image is linear, one 16-byte store per chunk
+#pragma unroll
+    for (int i = 0; i < MAXLOADS; ++i) {
+      int c = i * kWave + lane;
+      if (c < chunks) *reinterpret_cast<u32x4*>(lds32 + 4 * c) = r[i];
+    }
+  } else {  // even w: both words of a chunk belong to one block; padded rows are only 8-aligned
+#pragma unroll
+    for (int i = 0; i < MAXLOADS; ++i) {
+      int c = i * kWave + lane;
+      if (c < chunks) {
+        int wi = 2 * c;
+        int blk = wi / w;
+        int k = wi - blk * w;
+        uint32_t* dst = lds32 + 2 * (blk * stride + k);
+        u32x2 lo = {r[i].x, r[i].y}, hi = {r[i].z, r[i].w};
+        *reinterpret_cast<u32x2*>(dst) = lo;
+        *reinterpret_cast<u32x2*>(dst + 2) = hi;
+      }
+    }
+  }
+}
+
+// dword index of plane k's half for this lane: lane l <-> block l>>1; q = l&1 selects rows
+// 32q..32q+31, which live in the HIGH dword (q=0) or LOW dword (q=1) of each plane word.
+__device__ __forceinline__ int plane_base_dw(int w, int lane) {
+  return 2 * ((lane >> 1) * (w | 1)) + (1 - (lane & 1));
+}
+
+// ---- predicate on the encoded planes, streaming from LDS (any w, nothing kept in VGPRs) -----
+__device__ __forceinline__ uint32_t pred_single_from_lds(const uint32_t* lds32, int w, int lane,
+                                                         int op, uint32_t c) {
+  const uint32_t* p = lds32 + plane_base_dw(w, lane);
+  CmpState s{0u, ~0u};
+  int k = w - 1;
+  for (; k >= 3; k -= 4) {  // 4 independent LDS reads in flight per step
+    uint32_t x3 = p[2 * k], x2 = p[2 * k - 2], x1 = p[2 * k - 4], x0 = p[2 * k - 6];
+    cmp_step(s, x3, bit_mask(c, k));
+    cmp_step(s, x2, bit_mask(c, k - 1));
+    cmp_step(s, x1, bit_mask(c, k - 2));
+    cmp_step(s, x0, bit_mask(c, k - 3));
+  }
+  for (; k >= 0; --k) cmp_step(s, p[2 * k], bit_mask(c, k));
+  return cmp_select(s, op);
+}
+
+// IN: the planes are re-read from LDS once per constant, never from HBM (the reference makes K
+// full passes over the block's words as well, fle-encoding.h:8283-8290).
+template <typename CT>
+__device__ __forceinline__ uint32_t pred_in_from_lds(const uint32_t* lds32, int w, int lane,
+                                                     const CT* consts, int n_consts) {
+  const uint32_t* p = lds32 + plane_base_dw(w, lane);
+  uint32_t any = 0u;
+#pragma unroll 1
+  for (int j = 0; j < n_consts; ++j) {
+    const uint32_t c = (uint32_t)consts[j];
+    uint32_t eq = ~0u;
+    int k = w - 1;
+    for (; k >= 3; k -= 4) {
+      uint32_t x3 = p[2 * k], x2 = p[2 * k - 2], x1 = p[2 * k - 4], x0 = p[2 * k - 6];
+      eq &= ~(x3 ^ bit_mask(c, k));
+      eq &= ~(x2 ^ bit_mask(c, k - 1));
+      eq &= ~(x1 ^ bit_mask(c, k - 2));
+      eq &= ~(x0 ^ bit_mask(c, k - 3));
+    }
+    for (; k >= 0; --k) eq &= ~(p[2 * k] ^ bit_mask(c, k));
+    any |= eq;
+  }
+  return any;
+}
+
+__device__ __forceinline__ uint32_t pred_from_lds(const uint32_t* lds32, int w, int lane,
+                                                  const PredArgs& a) {
+  if (a.op != 5) return pred_single_from_lds(lds32, w, lane, a.op, a.consts[0]);
+  return pred_in_from_lds(lds32, w, lane, a.consts, a.n_consts);
+}
+
+// ---- predicate on planes already in registers (compile-time W), single constant ------------
+// (IN lists go through pred_from_lds: a K-deep loop around 32 live plane registers costs the
+// kernel a third of its occupancy.)
+template <int W>
+__device__ __forceinline__ uint32_t pred_from_regs(const uint32_t (&p)[W], const PredArgs& a) {
+  const uint32_t c = a.consts[0];
+  CmpState s{0u, ~0u};
+#pragma unroll
+  for (int k = W - 1; k >= 0; --k) cmp_step(s, p[k], bit_mask(c, k));
+  return cmp_select(s, a.op);
+}
+
+// Bitmap dword of this lane: bit j <-> row 32q+j of the block; rows >= n_rows are cleared.
+__device__ __forceinline__ uint32_t finish_bitmap_dword(uint32_t sel_msb_first, int64_t tile,
+                                                        int lane, int64_t n_rows) {
+  uint32_t r = bitrev32(sel_msb_first);
+  int64_t row0 = tile * kRowsPerTile + (int64_t)lane * 32;
+  int64_t valid = n_rows - row0;
+  if (valid < 32) r = valid <= 0 ? 0u : (r & ((1u << valid) - 1u));
+  return r;
+}
+
+// Number of bitmap dwords that exist: 2 * ceil(n/64).
+__device__ __forceinline__ int64_t bitmap_dwords(int64_t n_rows) { return 2 * ((n_rows + 63) / 64); }
+
+// ---- in-place, order-preserving compaction of a row tile held in LDS -------------------------
+// lds32 holds the 2048 values of the sub-tile in the padded row layout; bm = this lane's bitmap
+// dword (lane 2i, 2i+1 = low, high dword of block i's word).  Afterwards lds32[0..count) holds
+// the selected values in row order (linear layout).  Returns count (wave-uniform).
+__device__ __forceinline__ uint32_t compact_row_tile(uint32_t* lds32, uint32_t bm, int lane) {
+  uint32_t vals[32];
+  const int lane_dw = (lane >> 5) * kRowTileStrideDw + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) vals[i] = lds32[2 * i * kRowTileStrideDw + lane_dw];
+  wave_lds_fence();  // every read of the row tile is done before any compacted write lands
+  uint32_t run = 0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    uint32_t m_lo = __builtin_amdgcn_readlane(bm, 2 * i);
+    uint32_t m_hi = __builtin_amdgcn_readlane(bm, 2 * i + 1);
+    uint32_t pos = run + __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+    uint64_t m = ((uint64_t)m_hi << 32) | m_lo;
+    if ((m >> lane) & 1ull) lds32[pos] = vals[i];
+    run += __builtin_popcount(m_lo) + __builtin_popcount(m_hi);
+  }
+  return run;
+}
+
+// lds32[0..count) -> dst[0..count), coalesced; dst is 16-byte aligned.
+__device__ __forceinline__ void store_compacted(const uint32_t* lds32, uint32_t count,
+                                                uint32_t* __restrict__ dst, int lane) {
+  for (uint32_t p = 4u * lane; p < count; p += 4u * kWave) {
+    if (p + 4 <= count) {
+      *reinterpret_cast<u32x4*>(dst + p) = *reinterpret_cast<const u32x4*>(lds32 + p);
+    } else {
+      for (uint32_t e = p; e < count; ++e) dst[e] = lds32[e];
+    }
+  }
+}
+
+// Write this lane's 32 row values into the padded row tile (8 x 16-byte LDS stores).
+__device__ __forceinline__ void values_to_row_tile(uint32_t* lds32, int lane,
+                                                   const uint32_t (&v)[32]) {
+  uint32_t* dst = lds32 + lane * kRowTileStrideDw;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    u32x4 t = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+    *reinterpret_cast<u32x4*>(dst + 4 * i) = t;
+  }
+}
+
+template <int W>
+__device__ __forceinline__ void planes_from_lds(const uint32_t* lds32, int lane,
+                                                uint32_t (&p)[W]) {
+  const uint32_t* src = lds32 + plane_base_dw(W, lane);
+#pragma unroll
+  for (int k = 0; k < W; ++k) p[k] = src[2 * k];
+}
+
+}  // namespace ips

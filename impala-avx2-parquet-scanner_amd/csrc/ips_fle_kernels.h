@@ -1,0 +1,322 @@
+// ips_fle_kernels.h -- the templated FLE kernels (compile-time bit width W): fused scan, late
+// materialisation (select), full decode and encode.  Instantiated per W in ips_fle_*.hip.
+//
+// HBM roofline bounds every kernel here (there is no contraction, so no MFMA): per 2048-row
+// sub-tile a wave reads 256*W encoded bytes once, and writes 256 B of bitmap plus 4 bytes per
+// selected row (scan/select) or out_width bytes per row (decode).
+#pragma once
+#include "ips_device.h"
+
+namespace ips {
+
+enum ScanMode { kScanPredicate = 0, kScanGivenBitmap = 1, kScanInList = 2 };
+
+// Dictionary gather applied while values leave LDS: G = 0 none (store the code / raw value),
+// 4 / 8 = bytes per dictionary entry.
+template <int G>
+struct GatherT { using type = uint32_t; };
+template <>
+struct GatherT<8> { using type = uint64_t; };
+
+// ---------------------------------------------------------------------------------------------
+// Fused scan: predicate (or given bitmap) -> bitmap, selected rows decoded and written per batch.
+// Replaces EvalSimplePredicates + bitmap->skip-list + ReadValue(skip) of one column
+// (hdfs-parquet-scanner.cc:1837-1865, 1134-1181, 1006-1027; fle-encoding.h:8012-8066, 344-379).
+// ---------------------------------------------------------------------------------------------
+template <int W, int MODE, int G>
+__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kernel(
+    const uint64_t* __restrict__ enc, int64_t n_rows, PredArgs args,
+    uint32_t* __restrict__ bitmap32, const uint32_t* __restrict__ given_bitmap32,
+    typename GatherT<G>::type* __restrict__ batch_values, uint32_t* __restrict__ batch_counts,
+    const typename GatherT<G>::type* __restrict__ dict, uint32_t dict_entries,
+    int32_t* __restrict__ bad_index) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kRowTileBytes / 4];
+  constexpr int L = (16 * W + kWave - 1) / kWave;
+  const int lane = lane_id();
+  const int wave = wave_id();
+  uint32_t* lds32 = lds_all + wave * (kRowTileBytes / 4);
+
+  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int64_t total_words = ((n_rows + 63) / 64) * W;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t bm_dwords = bitmap_dwords(n_rows);
+  int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+
+  u32x4 r[L];
+  if (tile < tiles) tile_load<L>(enc, tile, W, total_words, lane, r);
+  while (tile < tiles) {
+    tile_to_lds<L>(lds32, W, lane, r);
+    const int64_t next = tile + stride;
+    if (next < tiles) tile_load<L>(enc, next, W, total_words, lane, r);  // register prefetch
+    wave_lds_fence();
+
+    const int64_t d = tile * 64 + lane;
+    uint32_t bm;
+    if (MODE == kScanInList) {  // IN: K passes over the planes in LDS, before they enter VGPRs
+      bm = finish_bitmap_dword(pred_from_lds(lds32, W, lane, args), tile, lane, n_rows);
+      if (d < bm_dwords) bitmap32[d] = bm;
+    }
+    uint32_t p[W];
+    planes_from_lds<W>(lds32, lane, p);
+    if (MODE == kScanPredicate) {
+      bm = finish_bitmap_dword(pred_from_regs<W>(p, args), tile, lane, n_rows);
+      if (d < bm_dwords) bitmap32[d] = bm;
+    } else if (MODE == kScanGivenBitmap) {
+      bm = d < bm_dwords ? given_bitmap32[d] : 0u;
+      bm = bitrev32(bm);  // finish_bitmap_dword reverses back; only the row mask is wanted
+      bm = finish_bitmap_dword(bm, tile, lane, n_rows);
+    }
+
+    uint32_t count = 0;
+    if (__builtin_amdgcn_ballot_w64(bm != 0u) != 0ull) {  // wave-uniform: any row selected
+      uint32_t v[32];
+      planes_to_values<W>(p, v);
+      wave_lds_fence();  // all plane reads precede the row-tile overwrite of the same region
+      values_to_row_tile(lds32, lane, v);
+      wave_lds_fence();
+      count = compact_row_tile(lds32, bm, lane);
+      wave_lds_fence();
+      if (G == 0) {
+        store_compacted(lds32, count, reinterpret_cast<uint32_t*>(batch_values) +
+                                          tile * kRowsPerTile, lane);
+      } else {
+        typename GatherT<G>::type* dst = batch_values + tile * kRowsPerTile;
+        int bad = 0;
+        for (uint32_t e = lane; e < count; e += kWave) {
+          uint32_t code = lds32[e];
+          if (code < dict_entries) dst[e] = dict[code]; else bad = 1;
+        }
+        if (bad && bad_index) *bad_index = 1;
+      }
+    }
+    if (lane == 0) batch_counts[tile] = count;
+    wave_lds_fence();  // LDS region is reused by the next sub-tile
+    tile = next;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Full decode: FleDecoder::Get x n via Unpack_w (fle-encoding.h:404-567, 569-7329), batch form.
+// OW = bytes per stored value (1, 2, 4) when G == 0; with G != 0 every code is looked up in the
+// dictionary and the G-byte entry is stored (DictDecoder::GetValue, dict-encoding.h:310-319).
+// ---------------------------------------------------------------------------------------------
+template <int W, int OW, int G>
+__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_decode_kernel(
+    const uint64_t* __restrict__ enc, int64_t n_rows, void* __restrict__ out,
+    const typename GatherT<G>::type* __restrict__ dict, uint32_t dict_entries,
+    int32_t* __restrict__ bad_index) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kRowTileBytes / 4];
+  constexpr int L = (16 * W + kWave - 1) / kWave;
+  const int lane = lane_id();
+  const int wave = wave_id();
+  uint32_t* lds32 = lds_all + wave * (kRowTileBytes / 4);
+
+  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int64_t total_words = ((n_rows + 63) / 64) * W;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+
+  u32x4 r[L];
+  if (tile < tiles) tile_load<L>(enc, tile, W, total_words, lane, r);
+  while (tile < tiles) {
+    tile_to_lds<L>(lds32, W, lane, r);
+    const int64_t next = tile + stride;
+    if (next < tiles) tile_load<L>(enc, next, W, total_words, lane, r);
+    wave_lds_fence();
+
+    uint32_t p[W];
+    planes_from_lds<W>(lds32, lane, p);
+    uint32_t v[32];
+    planes_to_values<W>(p, v);
+    wave_lds_fence();
+    values_to_row_tile(lds32, lane, v);
+    wave_lds_fence();
+
+    const int64_t row_base = tile * kRowsPerTile;
+    if (G != 0) {
+      typename GatherT<G>::type* dst = reinterpret_cast<typename GatherT<G>::type*>(out);
+      int bad = 0;
+#pragma unroll 4
+      for (int i = 0; i < 32; ++i) {
+        int rho = i * kWave + lane;
+        if (row_base + rho < n_rows) {
+          uint32_t code = lds32[row_tile_dw(rho)];
+          if (code < dict_entries) dst[row_base + rho] = dict[code]; else bad = 1;
+        }
+      }
+      if (bad && bad_index) *bad_index = 1;
+    } else if (OW == 4) {
+      uint32_t* dst = reinterpret_cast<uint32_t*>(out) + row_base;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        int rho = 4 * (i * kWave + lane);
+        u32x4 t = *reinterpret_cast<const u32x4*>(lds32 + row_tile_dw(rho));
+        int64_t valid = n_rows - (row_base + rho);
+        if (valid >= 4) {
+          *reinterpret_cast<u32x4*>(dst + rho) = t;
+        } else {
+          if (valid > 0) dst[rho] = t.x;
+          if (valid > 1) dst[rho + 1] = t.y;
+          if (valid > 2) dst[rho + 2] = t.z;
+        }
+      }
+    } else if (OW == 2) {
+      uint16_t* dst = reinterpret_cast<uint16_t*>(out) + row_base;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int rho = 8 * (i * kWave + lane);
+        u32x4 a = *reinterpret_cast<const u32x4*>(lds32 + row_tile_dw(rho));
+        u32x4 b = *reinterpret_cast<const u32x4*>(lds32 + row_tile_dw(rho + 4));
+        int64_t valid = n_rows - (row_base + rho);
+        if (valid >= 8) {
+          u32x4 t = {a.x | (a.y << 16), a.z | (a.w << 16), b.x | (b.y << 16), b.z | (b.w << 16)};
+          *reinterpret_cast<u32x4*>(dst + rho) = t;
+        } else {
+          uint32_t e[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < valid) dst[rho + j] = (uint16_t)e[j];
+        }
+      }
+    } else {
+      uint8_t* dst = reinterpret_cast<uint8_t*>(out) + row_base;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int rho = 16 * (i * kWave + lane);
+        u32x4 q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          q[j] = *reinterpret_cast<const u32x4*>(lds32 + row_tile_dw(rho + 4 * j));
+        int64_t valid = n_rows - (row_base + rho);
+        if (valid >= 16) {
+          u32x4 t;
+          t.x = q[0].x | (q[0].y << 8) | (q[0].z << 16) | (q[0].w << 24);
+          t.y = q[1].x | (q[1].y << 8) | (q[1].z << 16) | (q[1].w << 24);
+          t.z = q[2].x | (q[2].y << 8) | (q[2].z << 16) | (q[2].w << 24);
+          t.w = q[3].x | (q[3].y << 8) | (q[3].z << 16) | (q[3].w << 24);
+          *reinterpret_cast<u32x4*>(dst + rho) = t;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (4 * j + 0 < valid) dst[rho + 4 * j + 0] = (uint8_t)q[j].x;
+            if (4 * j + 1 < valid) dst[rho + 4 * j + 1] = (uint8_t)q[j].y;
+            if (4 * j + 2 < valid) dst[rho + 4 * j + 2] = (uint8_t)q[j].z;
+            if (4 * j + 3 < valid) dst[rho + 4 * j + 3] = (uint8_t)q[j].w;
+          }
+        }
+      }
+    }
+    wave_lds_fence();
+    tile = next;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Encode: FleEncoder::Put x n + Flush (fle-encoding.h:8315-8365, 9806-9812; Pack_w :8367-9803).
+// IW = bytes per input value.  Padding rows of the last block are encoded as zero.
+// ---------------------------------------------------------------------------------------------
+template <int W, int IW>
+__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_encode_kernel(const void* __restrict__ values,
+                                                              int64_t n_rows,
+                                                              uint64_t* __restrict__ enc) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kRowTileBytes / 4];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  uint32_t* lds32 = lds_all + wave * (kRowTileBytes / 4);
+
+  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int64_t total_words = ((n_rows + 63) / 64) * W;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  constexpr int RPL = 16 / IW;      // rows per 16-byte load
+  constexpr int NL = 32 / RPL;      // loads per lane per sub-tile
+
+  for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < tiles; tile += stride) {
+    const int64_t row_base = tile * kRowsPerTile;
+    // 1. values HBM -> row tile in LDS (coalesced 16-byte loads)
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      int rho = RPL * (i * kWave + lane);
+      int64_t valid = n_rows - (row_base + rho);
+      uint32_t e[RPL];
+      if (valid >= RPL) {
+        u32x4 t = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(values) +
+                                                  (row_base + rho) * IW);
+        uint32_t tw[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+          if (IW == 4) e[j] = tw[j];
+          else if (IW == 2) e[j] = (tw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+          else e[j] = (tw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+          uint32_t x = 0;
+          if (j < valid) {
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(values) +
+                                 (row_base + rho + j) * IW;
+            if (IW == 4) x = *reinterpret_cast<const uint32_t*>(src);
+            else if (IW == 2) x = *reinterpret_cast<const uint16_t*>(src);
+            else x = *src;
+          }
+          e[j] = x;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < RPL; j += 4) {
+        u32x4 t = {e[j], e[j + 1], e[j + 2], e[j + 3]};
+        *reinterpret_cast<u32x4*>(lds32 + row_tile_dw(rho + j)) = t;
+      }
+    }
+    wave_lds_fence();
+    // 2. lane-per-half-block: 32 values -> W plane halves
+    uint32_t v[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      u32x4 t = *reinterpret_cast<const u32x4*>(lds32 + lane * kRowTileStrideDw + 4 * i);
+      v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    }
+    uint32_t p[W];
+    values_to_planes<W>(v, p);
+    wave_lds_fence();
+    // 3. plane halves -> LDS plane image
+    {
+      uint32_t* dst = lds32 + plane_base_dw(W, lane);
+#pragma unroll
+      for (int k = 0; k < W; ++k) dst[2 * k] = p[k];
+    }
+    wave_lds_fence();
+    // 4. LDS plane image -> HBM, linear 16-byte stores
+    const int64_t w0 = tile * (int64_t)(kBlocksPerTile * W);
+    const int64_t left = total_words - w0;
+    constexpr int L = (16 * W + kWave - 1) / kWave;
+    constexpr int STRIDE = W | 1;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      int c = i * kWave + lane;
+      if (c < 16 * W && 2 * c < left) {
+        u32x4 t;
+        if (W & 1) {
+          t = *reinterpret_cast<const u32x4*>(lds32 + 4 * c);
+        } else {
+          int wi = 2 * c;
+          int blk = wi / W;
+          int k = wi - blk * W;
+          const uint32_t* src = lds32 + 2 * (blk * STRIDE + k);
+          u32x2 lo = *reinterpret_cast<const u32x2*>(src);
+          u32x2 hi = *reinterpret_cast<const u32x2*>(src + 2);
+          t.x = lo.x; t.y = lo.y; t.z = hi.x; t.w = hi.y;
+        }
+        if (2 * c + 1 < left) {
+          *reinterpret_cast<u32x4*>(enc + w0 + 2 * c) = t;
+        } else {
+          u32x2 h = {t.x, t.y};
+          *reinterpret_cast<u32x2*>(enc + w0 + 2 * c) = h;
+        }
+      }
+    }
+    wave_lds_fence();
+  }
+}
+
+}  // namespace ips

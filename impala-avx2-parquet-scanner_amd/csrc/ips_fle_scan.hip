@@ -1,0 +1,79 @@
+// ips_fle_scan.hip -- instantiations + launchers of the fused scan / select kernels for the bit
+// widths [IPS_WLO, IPS_WHI] (the file is compiled four times so the build parallelises).
+#include "ips_fle_kernels.h"
+#include "ips_host.h"
+
+#ifndef IPS_WLO
+#error "compile with -DIPS_WLO=.. -DIPS_PART=.."
+#endif
+#define IPS_CAT2(a, b) a##b
+#define IPS_CAT(a, b) IPS_CAT2(a, b)
+
+namespace ips {
+
+template <int W, int MODE, int G>
+static ips_status launch_one(const uint64_t* enc, int64_t n_rows, const PredArgs& args,
+                             uint32_t* bitmap32, const uint32_t* given32, void* batch_values,
+                             uint32_t* batch_counts, const void* dict, uint32_t dict_entries,
+                             int32_t* bad_index, hipStream_t s) {
+  using GT = typename GatherT<G>::type;
+  auto kern = fle_scan_kernel<W, MODE, G>;
+  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  int grid = grid_for_tiles(reinterpret_cast<const void*>(kern), tiles);
+  if (grid <= 0) return IPS_ERR_HIP;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, s, enc, n_rows, args, bitmap32, given32,
+                     reinterpret_cast<GT*>(batch_values), batch_counts,
+                     reinterpret_cast<const GT*>(dict), dict_entries, bad_index);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+template <int W>
+static ips_status launch_w(int mode, int gather, const uint64_t* enc, int64_t n_rows,
+                           const PredArgs& args, uint32_t* bitmap32, const uint32_t* given32,
+                           void* batch_values, uint32_t* batch_counts, const void* dict,
+                           uint32_t dict_entries, int32_t* bad_index, hipStream_t s) {
+#define IPS_ARGS enc, n_rows, args, bitmap32, given32, batch_values, batch_counts, dict, \
+                 dict_entries, bad_index, s
+  if (gather == 0) {
+    if (mode == kScanPredicate) return launch_one<W, kScanPredicate, 0>(IPS_ARGS);
+    if (mode == kScanInList) return launch_one<W, kScanInList, 0>(IPS_ARGS);
+    return launch_one<W, kScanGivenBitmap, 0>(IPS_ARGS);
+  }
+  if constexpr (W <= 16) {  // dictionaries hold <= 40000 entries: codes are <= 16 bits wide
+    if (mode == kScanPredicate) {
+      if (gather == 4) return launch_one<W, kScanPredicate, 4>(IPS_ARGS);
+      if (gather == 8) return launch_one<W, kScanPredicate, 8>(IPS_ARGS);
+    }
+    if (mode == kScanInList) {
+      if (gather == 4) return launch_one<W, kScanInList, 4>(IPS_ARGS);
+      if (gather == 8) return launch_one<W, kScanInList, 8>(IPS_ARGS);
+    }
+    if (mode == kScanGivenBitmap) {
+      if (gather == 4) return launch_one<W, kScanGivenBitmap, 4>(IPS_ARGS);
+      if (gather == 8) return launch_one<W, kScanGivenBitmap, 8>(IPS_ARGS);
+    }
+  }
+#undef IPS_ARGS
+  set_error("fused dictionary scan: unsupported bit width %d / gather %d / mode %d", W, gather,
+            mode);
+  return IPS_ERR_UNSUPPORTED;
+}
+
+ips_status IPS_CAT(launch_fle_scan_part_, IPS_PART)(
+    int w, int mode, int gather, const uint64_t* enc, int64_t n_rows, const PredArgs& args,
+    uint32_t* bitmap32, const uint32_t* given32, void* batch_values, uint32_t* batch_counts,
+    const void* dict, uint32_t dict_entries, int32_t* bad_index, hipStream_t s) {
+#define IPS_CASE(N)                                                                          \
+  case IPS_WLO + N:                                                                          \
+    return launch_w<IPS_WLO + N>(mode, gather, enc, n_rows, args, bitmap32, given32,         \
+                                 batch_values, batch_counts, dict, dict_entries, bad_index, s);
+  switch (w) {
+    IPS_CASE(0) IPS_CASE(1) IPS_CASE(2) IPS_CASE(3) IPS_CASE(4) IPS_CASE(5) IPS_CASE(6) IPS_CASE(7)
+  }
+#undef IPS_CASE
+  set_error("bit width %d outside part starting at %d", w, IPS_WLO);
+  return IPS_ERR_INVALID_ARG;
+}
+
+}  // namespace ips

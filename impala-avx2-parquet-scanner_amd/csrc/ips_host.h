@@ -1,0 +1,50 @@
+// ips_host.h -- host-side launch plumbing shared by the translation units of libips_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ips.h"
+#include "ips_device.h"
+
+namespace ips {
+
+// thread-local error text behind ips_last_error()
+void set_error(const char* fmt, ...);
+ips_status hip_fail(hipError_t e, const char* what);
+
+#define IPS_HIP_TRY(expr)                                   \
+  do {                                                      \
+    hipError_t _e = (expr);                                 \
+    if (_e != hipSuccess) return ::ips::hip_fail(_e, #expr); \
+  } while (0)
+
+#define IPS_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      ::ips::set_error(__VA_ARGS__);    \
+      return IPS_ERR_INVALID_ARG;       \
+    }                                   \
+  } while (0)
+
+// Blocks to launch for a grid-stride kernel over 'tiles' wave sub-tiles: enough to fill every CU
+// at the kernel's occupancy, never more than the work.  Occupancy is queried once per kernel.
+int grid_for_tiles(const void* kernel, int64_t tiles);
+int device_cus();
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- launchers implemented in the per-kernel translation units ----
+// mode: 0 single-constant predicate, 1 given bitmap, 2 IN list.  gather: 0 / 4 / 8 bytes per dictionary entry.
+ips_status launch_fle_scan(int w, int mode, int gather, const uint64_t* enc, int64_t n_rows,
+                           const PredArgs& args, uint32_t* bitmap32, const uint32_t* given32,
+                           void* batch_values, uint32_t* batch_counts, const void* dict,
+                           uint32_t dict_entries, int32_t* bad_index, hipStream_t s);
+ips_status launch_fle_decode(int w, int out_width, int gather, const uint64_t* enc, int64_t n_rows,
+                             void* out, const void* dict, uint32_t dict_entries,
+                             int32_t* bad_index, hipStream_t s);
+ips_status launch_fle_encode(int w, int in_width, const void* values, int64_t n_rows,
+                             uint64_t* enc, hipStream_t s);
+ips_status launch_fle_pred(int w, const uint64_t* enc, int64_t n_rows, const PredArgs& args,
+                           uint32_t* bitmap32, hipStream_t s);
+
+}  // namespace ips

@@ -1,0 +1,481 @@
+// ips_misc.hip -- the kernels that are not templated on the bit width: predicate-only FLE scan
+// (any w at run time), PLAIN-page predicates, bitmap algebra, IntersectBitset expand, batch
+// concatenation and the synthetic-column generator.  All HBM-bound streaming kernels.
+#include "ips_host.h"
+
+namespace ips {
+
+// =============================================================================================
+// FleDecoder::Eq/Lt/Le/Gt/Ge/In on the encoded planes (fle-encoding.h:7962-8313), bitmap only.
+// Nothing is decoded: per 64 rows the wave reads w words and writes one.
+// =============================================================================================
+__global__ __launch_bounds__(kThreads) void fle_pred_kernel(const uint64_t* __restrict__ enc,
+                                                            int64_t n_rows, int w, PredArgs args,
+                                                            uint32_t* __restrict__ bitmap32) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  uint32_t* lds32 = lds_dyn + wave * (plane_tile_bytes(w) / 4);
+
+  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int64_t total_words = ((n_rows + 63) / 64) * w;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t bm_dwords = bitmap_dwords(n_rows);
+  int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+
+  u32x4 r[8];
+  if (tile < tiles) tile_load<8>(enc, tile, w, total_words, lane, r);
+  while (tile < tiles) {
+    tile_to_lds<8>(lds32, w, lane, r);
+    const int64_t next = tile + stride;
+    if (next < tiles) tile_load<8>(enc, next, w, total_words, lane, r);
+    wave_lds_fence();
+    uint32_t bm = finish_bitmap_dword(pred_from_lds(lds32, w, lane, args), tile, lane, n_rows);
+    const int64_t d = tile * 64 + lane;
+    if (d < bm_dwords) bitmap32[d] = bm;
+    wave_lds_fence();
+    tile = next;
+  }
+}
+
+ips_status launch_fle_pred(int w, const uint64_t* enc, int64_t n_rows, const PredArgs& args,
+                           uint32_t* bitmap32, hipStream_t s) {
+  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  // LDS (4 * 256*(w|1) bytes per block) and VGPRs allow >= 4 blocks per CU for every w
+  int64_t want = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  int64_t cap = (int64_t)device_cus() * 4;
+  int grid = (int)(want < cap ? want : cap);
+  if (grid <= 0) return IPS_ERR_HIP;
+  size_t lds = (size_t)kWavesPerBlock * plane_tile_bytes(w);
+  hipLaunchKernelGGL(fle_pred_kernel, dim3(grid), dim3(kThreads), lds, s, enc, n_rows, w, args,
+                     bitmap32);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+// =============================================================================================
+// PLAIN fixed-width pages: ParquetPlainEncoder::Eq/Lt/Le/Gt/Ge (parquet-common.h:197-250, int8
+// :335-383, int16 :400-449).  bit = x OP literal (SQL order; the REFERENCE order is obtained by
+// the caller swapping LT<->GT, LE<->GE).  Lane loads 16 bytes = RPL rows; the RPL ballots are
+// re-interleaved into row order with a second round of ballots.
+// =============================================================================================
+template <typename T>
+struct PlainLit {
+  T v[16];
+  int32_t n;
+};
+
+template <typename T>
+__device__ __forceinline__ bool plain_cmp(T x, int op, const PlainLit<T>& lit) {
+  switch (op) {
+    case 0: return x == lit.v[0];
+    case 1: return x < lit.v[0];
+    case 2: return x <= lit.v[0];
+    case 3: return x > lit.v[0];
+    case 4: return x >= lit.v[0];
+    default: {
+      bool f = false;
+      for (int j = 0; j < lit.n; ++j) f = f || (x == lit.v[j]);
+      return f;
+    }
+  }
+}
+
+// T = compared type, S = slot type (int32_t for 4-byte slots, int64_t for 8-byte slots)
+template <typename T, typename S>
+__device__ __forceinline__ T slot_value(S raw) {
+  if constexpr (sizeof(T) == sizeof(S)) {
+    T t;
+    __builtin_memcpy(&t, &raw, sizeof(T));
+    return t;
+  } else {
+    return (T)raw;  // int8/int16: low bytes of the 4-byte slot, sign-extended by the cast
+  }
+}
+
+template <typename T, typename S>
+__global__ __launch_bounds__(kThreads) void plain_pred_kernel(const S* __restrict__ page,
+                                                              int64_t n_rows, int op,
+                                                              PlainLit<T> lit,
+                                                              uint64_t* __restrict__ bitmap) {
+  constexpr int RPL = 16 / sizeof(S);  // rows per lane per load: 4 or 2
+  const int lane = lane_id();
+  const int64_t wave_g = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
+  const int64_t waves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t rows_per_chunk = 64 * RPL;
+  const int64_t chunks = (n_rows + rows_per_chunk - 1) / rows_per_chunk;
+  const int64_t n_words = (n_rows + 63) / 64;
+
+  for (int64_t chunk = wave_g; chunk < chunks; chunk += waves) {
+    const int64_t row0 = chunk * rows_per_chunk + (int64_t)lane * RPL;
+    S raw[RPL];
+    if (row0 + RPL <= n_rows) {
+      u32x4 t = *reinterpret_cast<const u32x4*>(page + row0);
+      __builtin_memcpy(raw, &t, 16);
+    } else {
+#pragma unroll
+      for (int e = 0; e < RPL; ++e) raw[e] = row0 + e < n_rows ? page[row0 + e] : (S)0;
+    }
+    uint64_t m[RPL];
+#pragma unroll
+    for (int e = 0; e < RPL; ++e) {
+      bool b = (row0 + e < n_rows) && plain_cmp<T>(slot_value<T, S>(raw[e]), op, lit);
+      m[e] = __builtin_amdgcn_ballot_w64(b);  // bit l <-> row RPL*l + e of the chunk
+    }
+    // row 64*j + t of the chunk sits in ballot (t % RPL) at bit (64*j + t) / RPL
+    uint64_t sel;
+    if (RPL == 4) sel = (lane & 2) ? ((lane & 1) ? m[3] : m[2]) : ((lane & 1) ? m[1] : m[0]);
+    else sel = (lane & 1) ? m[1] : m[0];
+    uint64_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) {
+      int src = (64 * j + lane) / RPL;
+      uint64_t word = __builtin_amdgcn_ballot_w64(((sel >> src) & 1ull) != 0ull);
+      if (lane == j) mine = word;
+    }
+    const int64_t wi = chunk * RPL + lane;
+    if (lane < RPL && wi < n_words) bitmap[wi] = mine;
+  }
+}
+
+template <typename T, typename S>
+static ips_status launch_plain_t(const void* page, int64_t n_rows, int op, const void* literals,
+                                 int n_literals, uint64_t* bitmap, hipStream_t s) {
+  PlainLit<T> lit;
+  lit.n = n_literals;
+  for (int i = 0; i < 16; ++i) lit.v[i] = i < n_literals ? reinterpret_cast<const T*>(literals)[i] : T();
+  constexpr int RPL = 16 / sizeof(S);
+  int64_t chunks = (n_rows + 64 * RPL - 1) / (64 * RPL);
+  int64_t want = (chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+  int64_t cap = (int64_t)device_cus() * 8;
+  int grid = (int)(want < cap ? want : cap);
+  if (grid <= 0) return IPS_ERR_HIP;
+  hipLaunchKernelGGL((plain_pred_kernel<T, S>), dim3(grid), dim3(kThreads), 0, s,
+                     reinterpret_cast<const S*>(page), n_rows, op, lit, bitmap);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+ips_status launch_plain_pred(int type, const void* page, int64_t n_rows, int op,
+                             const void* literals, int n_literals, uint64_t* bitmap,
+                             hipStream_t s) {
+  switch (type) {
+    case IPS_T_INT8: return launch_plain_t<int8_t, int32_t>(page, n_rows, op, literals, n_literals, bitmap, s);
+    case IPS_T_INT16: return launch_plain_t<int16_t, int32_t>(page, n_rows, op, literals, n_literals, bitmap, s);
+    case IPS_T_INT32: return launch_plain_t<int32_t, int32_t>(page, n_rows, op, literals, n_literals, bitmap, s);
+    case IPS_T_INT64: return launch_plain_t<int64_t, int64_t>(page, n_rows, op, literals, n_literals, bitmap, s);
+    case IPS_T_FLOAT: return launch_plain_t<float, int32_t>(page, n_rows, op, literals, n_literals, bitmap, s);
+    case IPS_T_DOUBLE: return launch_plain_t<double, int64_t>(page, n_rows, op, literals, n_literals, bitmap, s);
+  }
+  set_error("plain_pred: bad type %d", type);
+  return IPS_ERR_INVALID_ARG;
+}
+
+// =============================================================================================
+// Bitmap algebra: AndOperate / OrOperate (simple-predicates.h:145-163), resize(n, value),
+// count().
+// =============================================================================================
+template <int OP>
+__global__ void bitmap_binop_kernel(uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
+                                    int64_t n_words) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words;
+       i += (int64_t)gridDim.x * blockDim.x)
+    a[i] = OP == 0 ? (a[i] & b[i]) : (a[i] | b[i]);
+}
+
+__global__ void bitmap_fill_kernel(uint64_t* __restrict__ a, int64_t n_rows, int value) {
+  const int64_t n_words = (n_rows + 63) / 64;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t w = value ? ~0ull : 0ull;
+    int64_t valid = n_rows - i * 64;
+    if (valid < 64) w &= (1ull << valid) - 1ull;
+    a[i] = w;
+  }
+}
+
+__global__ void bitmap_count_kernel(const uint64_t* __restrict__ a, int64_t n_rows,
+                                    unsigned long long* __restrict__ count) {
+  const int64_t n_words = (n_rows + 63) / 64;
+  unsigned long long c = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t w = a[i];
+    int64_t valid = n_rows - i * 64;
+    if (valid < 64) w &= (1ull << valid) - 1ull;
+    c += __builtin_popcountll(w);
+  }
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+  if (lane_id() == 0 && c) atomicAdd(count, c);
+}
+
+static int small_grid(int64_t items, int threads) {
+  int64_t want = (items + threads - 1) / threads;
+  int64_t cap = (int64_t)device_cus() * 8;
+  if (want < 1) want = 1;
+  return (int)(want < cap ? want : cap);
+}
+
+ips_status launch_bitmap_binop(int op, uint64_t* a, const uint64_t* b, int64_t n_words,
+                               hipStream_t s) {
+  if (n_words <= 0) return IPS_OK;
+  int grid = small_grid(n_words, 256);
+  if (op == 0) hipLaunchKernelGGL(bitmap_binop_kernel<0>, dim3(grid), dim3(256), 0, s, a, b, n_words);
+  else hipLaunchKernelGGL(bitmap_binop_kernel<1>, dim3(grid), dim3(256), 0, s, a, b, n_words);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+ips_status launch_bitmap_fill(uint64_t* a, int64_t n_rows, int value, hipStream_t s) {
+  if (n_rows <= 0) return IPS_OK;
+  hipLaunchKernelGGL(bitmap_fill_kernel, dim3(small_grid((n_rows + 63) / 64, 256)), dim3(256), 0,
+                     s, a, n_rows, value);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+ips_status launch_bitmap_count(const uint64_t* a, int64_t n_rows, int64_t* count, hipStream_t s) {
+  IPS_HIP_TRY(hipMemsetAsync(count, 0, 8, s));
+  if (n_rows <= 0) return IPS_OK;
+  hipLaunchKernelGGL(bitmap_count_kernel, dim3(small_grid((n_rows + 63) / 64, 256)), dim3(256), 0,
+                     s, a, n_rows, reinterpret_cast<unsigned long long*>(count));
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+// =============================================================================================
+// Device-wide exclusive scan of small per-item counts (three launches), shared by
+//  - IntersectBitset expand: items = bitmap words, count = popcount      (scanner.cc:326-331)
+//  - batch concatenation:   items = batches, count = batch_counts[b]      (scanner.cc:1151-1181)
+// A block handles kScanItems consecutive items; block totals are scanned by one block.
+// =============================================================================================
+constexpr int kScanThreads = 256;
+constexpr int kScanPerThread = 4;
+constexpr int kScanItems = kScanThreads * kScanPerThread;
+
+struct PopcItems {
+  const uint64_t* words;
+  int64_t n_rows;
+  __device__ __forceinline__ uint32_t operator()(int64_t i) const {
+    uint64_t w = words[i];
+    int64_t valid = n_rows - i * 64;
+    if (valid < 64) w &= (1ull << valid) - 1ull;
+    return __builtin_popcountll(w);
+  }
+};
+struct ArrayItems {
+  const uint32_t* counts;
+  __device__ __forceinline__ uint32_t operator()(int64_t i) const { return counts[i]; }
+};
+
+// exclusive prefix of this thread's value inside the block + block total (all threads)
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
+  __shared__ uint32_t wave_sums[kScanThreads / kWave];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+  for (int off = 1; off < kWave; off <<= 1) {
+    uint32_t t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  __syncthreads();  // wave_sums may still be read from a previous call
+  if (lane == kWave - 1) wave_sums[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (int i = 0; i < kScanThreads / kWave; ++i) {
+    if (i < wave) base += wave_sums[i];
+    tot += wave_sums[i];
+  }
+  *total = tot;
+  return base + incl - v;
+}
+
+template <typename Items>
+__global__ __launch_bounds__(kScanThreads) void scan_block_totals_kernel(Items items, int64_t n,
+                                                                         uint64_t* block_totals) {
+  const int64_t base = (int64_t)blockIdx.x * kScanItems + (int64_t)threadIdx.x * kScanPerThread;
+  uint32_t v = 0;
+#pragma unroll
+  for (int e = 0; e < kScanPerThread; ++e)
+    if (base + e < n) v += items(base + e);
+  uint32_t total;
+  block_exclusive_scan(v, &total);
+  if (threadIdx.x == 0) block_totals[blockIdx.x] = total;
+}
+
+// one block: block_totals[0..nb) -> exclusive prefixes in place; grand total -> *grand
+__global__ __launch_bounds__(kScanThreads) void scan_of_totals_kernel(uint64_t* block_totals,
+                                                                      int64_t nb,
+                                                                      int64_t* grand) {
+  __shared__ uint64_t part[kScanThreads];
+  const int64_t per = (nb + kScanThreads - 1) / kScanThreads;
+  const int64_t lo = (int64_t)threadIdx.x * per;
+  const int64_t hi = lo + per < nb ? lo + per : nb;
+  uint64_t sum = 0;
+  for (int64_t i = lo; i < hi; ++i) sum += block_totals[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t run = 0;
+    for (int i = 0; i < kScanThreads; ++i) {
+      uint64_t t = part[i];
+      part[i] = run;
+      run += t;
+    }
+    if (grand) *grand = (int64_t)run;
+  }
+  __syncthreads();
+  uint64_t run = part[threadIdx.x];
+  for (int64_t i = lo; i < hi; ++i) {
+    uint64_t t = block_totals[i];
+    block_totals[i] = run;
+    run += t;
+  }
+}
+
+// ---- IntersectBitset ------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t deposit_bits(uint64_t src, uint64_t mask) {
+  uint64_t out = 0;
+  while (mask) {  // j-th set bit of mask takes bit j of src
+    uint64_t low = mask & (0ull - mask);
+    if (src & 1ull) out |= low;
+    src >>= 1;
+    mask ^= low;
+  }
+  return out;
+}
+
+__global__ __launch_bounds__(kScanThreads) void bitmap_expand_kernel(
+    const uint64_t* __restrict__ root, const uint64_t* __restrict__ sub, int64_t n_rows,
+    const uint64_t* __restrict__ block_offsets, uint64_t* __restrict__ out) {
+  const int64_t n_words = (n_rows + 63) / 64;
+  const int64_t base = (int64_t)blockIdx.x * kScanItems + (int64_t)threadIdx.x * kScanPerThread;
+  PopcItems items{root, n_rows};
+  uint32_t pc[kScanPerThread];
+  uint32_t v = 0;
+#pragma unroll
+  for (int e = 0; e < kScanPerThread; ++e) {
+    pc[e] = base + e < n_words ? items(base + e) : 0u;
+    v += pc[e];
+  }
+  uint32_t total;
+  uint64_t off = block_offsets[blockIdx.x] + block_exclusive_scan(v, &total);
+#pragma unroll
+  for (int e = 0; e < kScanPerThread; ++e) {
+    if (base + e < n_words) {
+      uint64_t m = root[base + e];
+      int64_t valid = n_rows - (base + e) * 64;
+      if (valid < 64) m &= (1ull << valid) - 1ull;
+      uint64_t bits = 0;
+      if (pc[e]) {
+        const int sh = (int)(off & 63);
+        bits = sub[off >> 6] >> sh;
+        if (sh + (int)pc[e] > 64) bits |= sub[(off >> 6) + 1] << (64 - sh);
+      }
+      out[base + e] = deposit_bits(bits, m);
+      off += pc[e];
+    }
+  }
+}
+
+ips_status launch_bitmap_expand(const uint64_t* root, const uint64_t* sub, int64_t n_rows,
+                                uint64_t* out, void* workspace, hipStream_t s) {
+  const int64_t n_words = (n_rows + 63) / 64;
+  if (n_words <= 0) return IPS_OK;
+  const int64_t nb = (n_words + kScanItems - 1) / kScanItems;
+  uint64_t* totals = reinterpret_cast<uint64_t*>(workspace);
+  hipLaunchKernelGGL((scan_block_totals_kernel<PopcItems>), dim3((unsigned)nb), dim3(kScanThreads),
+                     0, s, PopcItems{root, n_rows}, n_words, totals);
+  hipLaunchKernelGGL(scan_of_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, totals, nb,
+                     (int64_t*)nullptr);
+  hipLaunchKernelGGL(bitmap_expand_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, s, root, sub,
+                     n_rows, totals, out);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+size_t scan_workspace_bytes(int64_t items) {
+  return (size_t)((items + kScanItems - 1) / kScanItems + 1) * 8;
+}
+
+// ---- batch concatenation --------------------------------------------------------------------
+template <typename V>
+__global__ __launch_bounds__(kScanThreads) void batches_compact_kernel(
+    const V* __restrict__ batch_values, const uint32_t* __restrict__ counts, int64_t n_batches,
+    const uint64_t* __restrict__ block_offsets, V* __restrict__ dense) {
+  // one wave per batch inside a block of kScanItems batches; offsets via the block scan
+  __shared__ uint64_t offs[kScanItems];
+  const int64_t base = (int64_t)blockIdx.x * kScanItems + (int64_t)threadIdx.x * kScanPerThread;
+  uint32_t c[kScanPerThread];
+  uint32_t v = 0;
+#pragma unroll
+  for (int e = 0; e < kScanPerThread; ++e) {
+    c[e] = base + e < n_batches ? counts[base + e] : 0u;
+    v += c[e];
+  }
+  uint32_t total;
+  uint64_t off = block_offsets[blockIdx.x] + block_exclusive_scan(v, &total);
+#pragma unroll
+  for (int e = 0; e < kScanPerThread; ++e) {
+    offs[threadIdx.x * kScanPerThread + e] = off;
+    off += c[e];
+  }
+  __syncthreads();
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  for (int b = wave; b < kScanItems; b += kScanThreads / kWave) {
+    const int64_t batch = (int64_t)blockIdx.x * kScanItems + b;
+    if (batch >= n_batches) break;
+    const uint32_t cnt = counts[batch];
+    const V* src = batch_values + batch * kRowsPerTile;
+    V* dst = dense + offs[b];
+    for (uint32_t i = lane; i < cnt; i += kWave) dst[i] = src[i];
+  }
+}
+
+ips_status launch_batches_compact(const void* batch_values, const uint32_t* counts,
+                                  int64_t n_batches, int value_width, void* dense,
+                                  int64_t* total, void* workspace, hipStream_t s) {
+  if (n_batches <= 0) {
+    IPS_HIP_TRY(hipMemsetAsync(total, 0, 8, s));
+    return IPS_OK;
+  }
+  const int64_t nb = (n_batches + kScanItems - 1) / kScanItems;
+  uint64_t* totals = reinterpret_cast<uint64_t*>(workspace);
+  hipLaunchKernelGGL((scan_block_totals_kernel<ArrayItems>), dim3((unsigned)nb),
+                     dim3(kScanThreads), 0, s, ArrayItems{counts}, n_batches, totals);
+  hipLaunchKernelGGL(scan_of_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, totals, nb, total);
+  if (value_width == 4)
+    hipLaunchKernelGGL((batches_compact_kernel<uint32_t>), dim3((unsigned)nb), dim3(kScanThreads),
+                       0, s, reinterpret_cast<const uint32_t*>(batch_values), counts, n_batches,
+                       totals, reinterpret_cast<uint32_t*>(dense));
+  else
+    hipLaunchKernelGGL((batches_compact_kernel<uint64_t>), dim3((unsigned)nb), dim3(kScanThreads),
+                       0, s, reinterpret_cast<const uint64_t*>(batch_values), counts, n_batches,
+                       totals, reinterpret_cast<uint64_t*>(dense));
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+// =============================================================================================
+// Synthetic column generator: x_i = splitmix64(seed + i), value = x_i & mask.
+// =============================================================================================
+__global__ void synth_kernel(uint64_t seed, int64_t n, uint32_t mask, uint32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t z = seed + (uint64_t)i + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    out[i] = (uint32_t)z & mask;
+  }
+}
+
+ips_status launch_synth(uint64_t seed, int64_t n, uint32_t mask, uint32_t* out, hipStream_t s) {
+  if (n <= 0) return IPS_OK;
+  hipLaunchKernelGGL(synth_kernel, dim3(small_grid(n, 256)), dim3(256), 0, s, seed, n, mask, out);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+}  // namespace ips

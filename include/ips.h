@@ -1,0 +1,240 @@
+/*
+ * include/ips.h -- C-ABI of libips_hip.so: MI355X (gfx950) implementation of the bit-sliced
+ * "FLE" / sorted-dictionary decode + vectorised predicate -> selection-bitmap hot path of
+ * zuowang/Impala-avx2-parquet-scanner.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch/HIP types.  Every entry
+ * point names the reference interface it replaces (file:line relative to the reference root).
+ * INTEGRATION.md shows the reference-side binding for each one.
+ *
+ * Conventions
+ *  - "d_" pointers are device (HBM) pointers, 16-byte aligned; "h_" / unprefixed small arrays
+ *    are host pointers.  The caller owns every buffer; the library owns only the opaque handles
+ *    it returns (the reference decoders likewise never own page bytes, dict-encoding.h:179-181).
+ *  - Bitmaps are arrays of little-endian uint64 words, bit (r % 64) of word (r / 64) <-> row r,
+ *    1 = row passes (boost::dynamic_bitset<> block order; "skip_bitset" in the reference is a
+ *    misnomer, hdfs-parquet-scanner.cc:1139-1143).  ceil(n_rows/64) words are written; bits
+ *    >= n_rows of the last word are zero.
+ *  - FLE layout (fle-encoding.h:8338-8340, 425-430): blocks of 64 values; a block of bit width w
+ *    is w consecutive uint64 words; word i holds bit i of all 64 values, value k at bit 63-k.
+ *    Encoded size is ceil(n/64)*w*8 bytes (fle-encoding.h:9806-9812); kernels never read past it.
+ *  - All functions return IPS_OK (0) or an error code; ips_last_error() gives the message of
+ *    the calling thread's last failure.  No exceptions cross the ABI.  Calls are asynchronous on
+ *    'stream' (a hipStream_t passed as void*; NULL = default stream) unless stated.
+ *  - Entry points are thread-safe; handles are thread-compatible (one thread at a time), like
+ *    the reference's per-scanner-thread decoders (expr-context.h:39-42).
+ */
+#ifndef IPS_H
+#define IPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPS_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+  IPS_OK = 0,
+  IPS_ERR_INVALID_ARG = 1, /* bad bit width / op / type / NULL / misaligned pointer */
+  IPS_ERR_UNSUPPORTED = 2,
+  IPS_ERR_HIP = 3,         /* a HIP runtime call failed (no device, launch failure, ...) */
+  IPS_ERR_NOMEM = 4,
+  IPS_ERR_OUT_OF_DATA = 5, /* FleDecoder::Get returning false, fle-encoding.h:350,407 */
+  IPS_ERR_BAD_INDEX = 6    /* dictionary code >= num_entries, dict-encoding.h:316 */
+} ips_status;
+
+/* FleDecoder::{Eq,Lt,Le,Gt,Ge,In}, fle-encoding.h:150-155; SimplePredicate leaves,
+ * simple-predicates.h:68-143; fn names eq/lt/le/gt/ge/in_set_lookup, scalar-fn-call.cc:945-962 */
+typedef enum { IPS_OP_EQ = 0, IPS_OP_LT = 1, IPS_OP_LE = 2, IPS_OP_GT = 3, IPS_OP_GE = 4,
+               IPS_OP_IN = 5 } ips_op;
+
+/* Column value types on the path (explicit instantiations hdfs-parquet-scanner.cc:1909-2058,
+ * minus string/decimal/timestamp which are out of scope). */
+typedef enum { IPS_T_INT8 = 0, IPS_T_INT16 = 1, IPS_T_INT32 = 2, IPS_T_INT64 = 3,
+               IPS_T_FLOAT = 4, IPS_T_DOUBLE = 5 } ips_type;
+
+/* PLAIN-page predicate operand order.  REFERENCE reproduces parquet-common.h:203,214,225,236,247
+ * (bit = literal OP x, operands reversed); SQL is bit = x OP literal. */
+typedef enum { IPS_SEM_REFERENCE = 0, IPS_SEM_SQL = 1 } ips_semantics;
+
+/* Result of a dictionary literal -> code translation (dict-encoding.h:461-541). */
+typedef enum { IPS_XL_ALL_FALSE = 0, IPS_XL_ALL_TRUE = 1, IPS_XL_FLE = 2 } ips_xl_kind;
+
+typedef void* ips_stream;
+typedef struct ips_dict ips_dict;
+
+/* Rows per selection batch of the fused scan: each batch's selected values are written densely,
+ * in row order, at d_batch_values + batch*IPS_BATCH_ROWS (the scanner hands row batches upstream,
+ * hdfs-parquet-scanner.cc:1092-1182; the reference batch is 1024 rows, :1838). */
+#define IPS_BATCH_ROWS 2048
+#define IPS_MAX_IN_LIST 256
+
+/* ---- library / device ---------------------------------------------------------------------- */
+int ips_version(void);
+const char* ips_last_error(void);
+ips_status ips_device_count(int* count);
+ips_status ips_set_device(int device);
+/* name, CU count, HBM bytes; any out pointer may be NULL */
+ips_status ips_device_info(char* name, int name_len, int* compute_units, int64_t* hbm_bytes);
+
+/* Device memory / stream plumbing for hosts that do not link HIP themselves (the C++ facade). */
+ips_status ips_malloc(void** d_ptr, size_t bytes);
+ips_status ips_free(void* d_ptr);
+ips_status ips_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, ips_stream stream);
+ips_status ips_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, ips_stream stream);
+ips_status ips_memset(void* d_dst, int value, size_t bytes, ips_stream stream);
+ips_status ips_stream_create(ips_stream* stream);
+ips_status ips_stream_destroy(ips_stream stream);
+ips_status ips_stream_synchronize(ips_stream stream);
+
+/* ---- FLE codec ----------------------------------------------------------------------------- */
+/* FleEncoder::Flush() return value, fle-encoding.h:9806-9812 (fle-test.cc:219,224,238). */
+int64_t ips_fle_encoded_bytes(int64_t n_rows, int bit_width);
+
+/* FleEncoder::Put x n + Flush, fle-encoding.h:8315-8365, 9806-9812 (Pack_w :8367-9803).
+ * d_values: n_rows unsigned values of in_width bytes (1, 2 or 4), each < 2^bit_width.
+ * Padding rows of the last block are written as zero (the reference leaves them undefined). */
+ips_status ips_fle_encode(const void* d_values, int in_width, int64_t n_rows, int bit_width,
+                          void* d_enc, ips_stream stream);
+
+/* FleDecoder::Get x n (batch form), fle-encoding.h:404-567 via Unpack_w :569-7329.
+ * out_width: bytes per decoded value: 1 (bit_width<=8), 2 (<=16) or 4; the reference's staging
+ * widths (fle-encoding.h:365-371) are the minimum legal widths. */
+ips_status ips_fle_decode(const void* d_enc, int64_t n_rows, int bit_width, void* d_out,
+                          int out_width, ips_stream stream);
+
+/* FleDecoder::Eq/Lt/Le/Gt/Ge/In on rows [0, n_rows), fle-encoding.h:7962-8313.
+ * consts: n_consts (1, or 1..IPS_MAX_IN_LIST for IN) unsigned constants < 2^bit_width (host).
+ * Evaluated directly on the encoded bit-planes; nothing is decoded. */
+ips_status ips_fle_pred(const void* d_enc, int64_t n_rows, int bit_width, ips_op op,
+                        const uint64_t* consts, int n_consts, uint64_t* d_bitmap,
+                        ips_stream stream);
+
+/* Fused scan of one FLE column chunk: predicate -> bitmap, plus late materialisation of the
+ * selected rows in the same pass over the encoded bytes (EvalSimplePredicates + ReadValue(skip),
+ * hdfs-parquet-scanner.cc:1837-1865, 1134-1181, 1006-1027; FleDecoder::Get(val, skip)
+ * fle-encoding.h:344-379).
+ *   d_bitmap        ceil(n/64) words (may not be NULL)
+ *   d_batch_values  ceil(n/IPS_BATCH_ROWS) batches of IPS_BATCH_ROWS slots of 4 bytes; batch b
+ *                   holds its d_batch_counts[b] selected values first, in row order
+ *   d_batch_counts  uint32 per batch */
+ips_status ips_fle_scan(const void* d_enc, int64_t n_rows, int bit_width, ips_op op,
+                        const uint64_t* consts, int n_consts, uint64_t* d_bitmap,
+                        uint32_t* d_batch_values, uint32_t* d_batch_counts, ips_stream stream);
+
+/* Late materialisation against an existing bitmap (e.g. the AND of several columns' predicates):
+ * per batch, the values of the rows whose bitmap bit is set (ReadValue(skip) per selected row,
+ * hdfs-parquet-scanner.cc:1151-1181).  Same output layout as ips_fle_scan. */
+ips_status ips_fle_select(const void* d_enc, int64_t n_rows, int bit_width,
+                          const uint64_t* d_bitmap, uint32_t* d_batch_values,
+                          uint32_t* d_batch_counts, ips_stream stream);
+
+/* Concatenate the batches of ips_fle_scan / ips_fle_select / ips_dict_scan into one dense array
+ * (tuple order of AssembleRows, hdfs-parquet-scanner.cc:1151-1181).  value_width 4 or 8.
+ * d_total receives the number of values (int64).  Workspace: ips_batches_workspace_bytes(). */
+size_t ips_batches_workspace_bytes(int64_t n_rows);
+ips_status ips_batches_compact(const void* d_batch_values, const uint32_t* d_batch_counts,
+                               int64_t n_rows, int value_width, void* d_dense, int64_t* d_total,
+                               void* d_workspace, ips_stream stream);
+
+/* ---- sorted dictionary codec ---------------------------------------------------------------- */
+/* DictDecoder<T>::DictDecoder(dict_buffer, dict_len, fixed_len_size), dict-encoding.h:449-459:
+ * PLAIN-decodes the (ascending) dictionary page; keeps a host copy for literal translation and a
+ * device copy for gathers.  Synchronous. */
+ips_status ips_dict_open(const void* h_dict_page, int64_t dict_len, ips_type type,
+                         ips_dict** dict);
+ips_status ips_dict_close(ips_dict* dict);
+/* DictDecoder::num_entries(), dict-encoding.h:214 */
+int64_t ips_dict_num_entries(const ips_dict* dict);
+/* DictEncoderBase::bit_width(), dict-encoding.h:76-80 with BitUtil::Log2, bit-util.h:128-140 */
+int ips_dict_bit_width(int64_t num_entries);
+
+/* Literal -> code translation of DictDecoder<T>::Eq/Lt/Le/Gt/Ge/In, dict-encoding.h:461-541.
+ * literals: n_literals values of the dictionary's type (host).  codes must hold n_literals. */
+ips_status ips_dict_translate(const ips_dict* dict, ips_op op, const void* literals,
+                              int n_literals, ips_xl_kind* kind, ips_op* fle_op,
+                              uint64_t* codes, int* n_codes);
+
+/* DictDecoder<T>::Eq/Lt/Le/Gt/Ge/In on a REQUIRED column's data page, dict-encoding.h:461-541.
+ * d_codes_enc: the FLE blocks of the page, i.e. the payload AFTER the 1-byte bit-width header
+ * that DictDecoderBase::SetData strips (dict-encoding.h:185-192); bit_width is that header byte. */
+ips_status ips_dict_pred(const ips_dict* dict, const void* d_codes_enc, int64_t n_rows,
+                         int bit_width, ips_op op, const void* literals, int n_literals,
+                         uint64_t* d_bitmap, ips_stream stream);
+
+/* DictDecoder<T>::GetValue x n, dict-encoding.h:310-319: d_out[r] = dict[code_r] (sizeof(T)
+ * bytes each; int8/int16 as 1/2 bytes).  *d_bad_index (int32, may be NULL) is set non-zero if a
+ * code >= num_entries was met (the reference returns false, :316). */
+ips_status ips_dict_decode(const ips_dict* dict, const void* d_codes_enc, int64_t n_rows,
+                           int bit_width, void* d_out, int32_t* d_bad_index, ips_stream stream);
+
+/* Fused dictionary scan: ips_dict_pred + gather of the selected rows' values in one pass.
+ * Batch slots are sizeof(T) bytes (T = dictionary type, int8/int16 widened to 4). */
+ips_status ips_dict_scan(const ips_dict* dict, const void* d_codes_enc, int64_t n_rows,
+                         int bit_width, ips_op op, const void* literals, int n_literals,
+                         uint64_t* d_bitmap, void* d_batch_values, uint32_t* d_batch_counts,
+                         ips_stream stream);
+
+/* ---- PLAIN fixed-width pages ---------------------------------------------------------------- */
+/* ParquetPlainEncoder::ByteSize(ColumnType), parquet-common.h:92-117: 4 or 8 */
+int ips_plain_stride(ips_type type);
+/* ParquetPlainEncoder::Eq/Lt/Le/Gt/Ge<T>, parquet-common.h:197-250 (int8 :335-383, int16
+ * :400-449).  IN: the reference body is empty (parquet-common.h:252-255); REFERENCE semantics
+ * returns IPS_ERR_UNSUPPORTED for it, SQL semantics evaluates it. */
+ips_status ips_plain_pred(const void* d_page, int64_t n_rows, ips_type type, ips_op op,
+                          const void* literals, int n_literals, ips_semantics semantics,
+                          uint64_t* d_bitmap, ips_stream stream);
+
+/* ---- bitmap algebra (SimplePredicate tree, simple-predicates.h:145-163) --------------------- */
+ips_status ips_bitmap_and(uint64_t* d_a, const uint64_t* d_b, int64_t n_rows, ips_stream stream);
+ips_status ips_bitmap_or(uint64_t* d_a, const uint64_t* d_b, int64_t n_rows, ips_stream stream);
+/* dynamic_bitset::resize(n, value) as used by dict-encoding.h:466,476,478 */
+ips_status ips_bitmap_fill(uint64_t* d_a, int64_t n_rows, int value, ips_stream stream);
+/* dynamic_bitset::count(), hdfs-parquet-scanner.cc:344,1125; d_count is int64 */
+ips_status ips_bitmap_count(const uint64_t* d_a, int64_t n_rows, int64_t* d_count,
+                            ips_stream stream);
+/* ColumnReader::IntersectBitset, hdfs-parquet-scanner.cc:326-331: the j-th set bit of d_root
+ * takes bit j of d_sub; cleared bits stay 0.  Workspace: ips_expand_workspace_bytes(n_rows). */
+size_t ips_expand_workspace_bytes(int64_t n_rows);
+ips_status ips_bitmap_expand(const uint64_t* d_root, const uint64_t* d_sub, int64_t n_rows,
+                             uint64_t* d_out, void* d_workspace, ips_stream stream);
+
+/* ---- fused predicate program (EvalSimplePredicates, hdfs-parquet-scanner.cc:1837-1865) ------ */
+typedef enum { IPS_NODE_LEAF = 0, IPS_NODE_AND = 1, IPS_NODE_OR = 2 } ips_node_kind;
+typedef enum { IPS_COL_FLE = 0, IPS_COL_PLAIN = 1 } ips_col_encoding;
+
+typedef struct {
+  int32_t encoding;      /* ips_col_encoding */
+  int32_t bit_width;     /* FLE: 1..32 */
+  int32_t type;          /* PLAIN: ips_type */
+  int32_t reserved;
+  const void* d_data;    /* FLE blocks or PLAIN page */
+} ips_column;
+
+/* Postfix program: leaves push a bitmap, AND/OR pop two and push one (AndOperate / OrOperate,
+ * simple-predicates.h:145-163); a conjunct list is a chain of ANDs (:1857-1862). */
+typedef struct {
+  int32_t kind;          /* ips_node_kind */
+  int32_t column;        /* leaf: index into cols */
+  int32_t op;            /* leaf: ips_op (FLE: on codes/values; PLAIN: SQL semantics) */
+  int32_t n_consts;      /* leaf: 1, or 1..16 for IN */
+  uint64_t consts[16];   /* leaf: FLE constants, or PLAIN literal bit patterns */
+} ips_node;
+
+#define IPS_PROGRAM_MAX_NODES 32
+#define IPS_PROGRAM_MAX_COLS 8
+ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const ips_column* cols, int n_cols,
+                            int64_t n_rows, uint64_t* d_bitmap, ips_stream stream);
+
+/* ---- synthetic data (bench / tests) --------------------------------------------------------- */
+/* d_out[i] = splitmix64(seed + i) & mask, as uint32 (SURVEY 8d generator). */
+ips_status ips_synth_splitmix_u32(uint64_t seed, int64_t n, uint32_t mask, uint32_t* d_out,
+                                  ips_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPS_H */

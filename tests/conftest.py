@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def O():
+    """The CPU checker (oracle/): plain-C restatement of the reference algorithms."""
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def ips():
+    """The product package; loading it requires the built libips_hip.so (no fallback)."""
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+@pytest.fixture(scope="session")
+def capi(ips):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test selected but no GPU is visible")
+    ips.capi.lib()
+    return ips.capi

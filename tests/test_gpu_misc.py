@@ -1,0 +1,219 @@
+"""GPU parity tests of the dictionary path, PLAIN-page predicates, bitmap algebra, the
+IntersectBitset expand and the fused predicate program, all through the C-ABI vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_words(a):
+    a = np.ascontiguousarray(a)
+    if a.size == 0:
+        return torch.zeros(2, dtype=torch.int64, device="cuda")
+    return torch.from_numpy(a.view(np.int64)).cuda()
+
+
+def words(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def bits_of(w, n):
+    return np.unpackbits(np.ascontiguousarray(w).view(np.uint8), bitorder="little")[:n].astype(bool)
+
+
+def page_blocks(data_page):
+    """DictDecoderBase::SetData strips the 1-byte width header (dict-encoding.h:185-192)."""
+    return int(data_page[0]), np.frombuffer(data_page[1:].tobytes(), dtype=np.uint64)
+
+
+TYPES = ["T_INT8", "T_INT16", "T_INT32", "T_INT64", "T_FLOAT", "T_DOUBLE"]
+
+
+def make_dict_column(O, t, rng, n, distinct):
+    npt = O.NP_TYPES[t]
+    if np.issubdtype(npt, np.integer):
+        info = np.iinfo(npt)
+        lo, hi = max(info.min, -(10 ** 9)), min(info.max, 10 ** 9)
+        pool = rng.choice(np.arange(lo, hi, max((hi - lo) // (4 * distinct), 1)), distinct, replace=False)
+    else:
+        pool = np.unique(rng.normal(0, 1000, 2 * distinct).astype(npt))[:distinct]
+    pool = pool.astype(npt)
+    vals = pool[rng.integers(0, len(pool), n)]
+    vals[:len(pool)] = pool
+    return vals
+
+
+@pytest.mark.parametrize("type_name", TYPES)
+def test_dict_pred_decode_scan(capi, O, type_name):
+    t = getattr(O, type_name)
+    rng = np.random.default_rng(40 + t)
+    distinct = 100 if t == O.T_INT8 else 300
+    n = 5000
+    vals = make_dict_column(O, t, rng, n, distinct)
+    d, dict_page, codes = O.dict_build(vals, t)
+    data = O.dict_write_data(codes, len(d))
+    bw, blocks = page_blocks(data)
+    assert bw == capi.dict_bit_width(len(d))
+    dd = capi.Dict(dict_page, t)
+    assert dd.num_entries == len(d)
+    enc = dev_words(blocks)
+
+    out, bad = dd.decode(enc, n, bw)
+    got = out.cpu().numpy().astype(O.NP_TYPES[t])
+    assert int(bad.item()) == 0 and np.array_equal(got, vals)
+
+    below = d[0] - 1 if d[0] > np.finfo(np.float32).min else d[0]
+    absent = (d[10] + d[11]) / 2 if not np.issubdtype(d.dtype, np.integer) else None
+    lits = [below, d[0], d[len(d) // 2], d[-1], d[-1] + 1]
+    if absent is not None:
+        lits.append(absent)
+    lits = np.array(lits).astype(O.NP_TYPES[t])
+    for lit in lits:
+        for op in (O.OP_EQ, O.OP_LT, O.OP_LE, O.OP_GT, O.OP_GE):
+            kind, fle_op, xcodes = O.dict_translate(d, t, op, lit)
+            got_kind, got_op, got_codes = dd.translate(op, lit)
+            assert got_kind == kind
+            if kind == O.XL_FLE:
+                assert (got_op, got_codes) == (fle_op, [int(x) for x in xcodes])
+            ref = O.dict_pred(d, t, data, n, op, lit)
+            assert np.array_equal(words(dd.pred(enc, n, bw, op, lit)), ref), (type_name, op, lit)
+            bitmap, bvals, counts = dd.scan(enc, n, bw, op, lit)
+            assert np.array_equal(words(bitmap), ref)
+            dense = capi.batches_compact(bvals, counts, n).cpu().numpy().astype(O.NP_TYPES[t])
+            assert np.array_equal(dense, vals[bits_of(ref, n)]), (type_name, op, lit)
+    in_list = np.array([d[3], d[-2], d[0] - 1 if np.issubdtype(d.dtype, np.integer) else d[0] - 0.5,
+                        d[7]]).astype(O.NP_TYPES[t])
+    ref = O.dict_pred(d, t, data, n, O.OP_IN, in_list)
+    assert np.array_equal(words(dd.pred(enc, n, bw, O.OP_IN, in_list)), ref)
+    bitmap, bvals, counts = dd.scan(enc, n, bw, O.OP_IN, in_list)
+    assert np.array_equal(words(bitmap), ref)
+    dense = capi.batches_compact(bvals, counts, n).cpu().numpy().astype(O.NP_TYPES[t])
+    assert np.array_equal(dense, vals[bits_of(ref, n)])
+    dd.close()
+
+
+def test_dict_bad_index_flag(capi, O):
+    """A code >= num_entries: the reference's GetValue returns false (dict-encoding.h:316)."""
+    d = np.arange(5, dtype=np.int32)
+    dd = capi.Dict(d.view(np.uint8), O.T_INT32)
+    codes = np.array([0, 1, 7, 2] * 20, dtype=np.uint32)      # 7 >= 5
+    enc = dev_words(O.fle_encode(codes, 3))
+    _, bad = dd.decode(enc, len(codes), 3)
+    assert int(bad.item()) != 0
+    dd.close()
+
+
+@pytest.mark.parametrize("type_name", TYPES)
+def test_plain_pred(capi, O, type_name):
+    t = getattr(O, type_name)
+    rng = np.random.default_rng(60 + t)
+    npt = O.NP_TYPES[t]
+    for n in (1, 63, 64, 65, 255, 256, 257, 5000, 20011):
+        if np.issubdtype(npt, np.integer):
+            info = np.iinfo(npt)
+            vals = rng.integers(max(info.min, -500), min(info.max, 500), n).astype(npt)
+        else:
+            vals = rng.normal(0, 100, n).astype(npt)
+        page = O.plain_encode(vals, t)
+        d_page = torch.from_numpy(np.concatenate([page, np.zeros(16, np.uint8)])).cuda()
+        lit = vals[n // 2]
+        for op in (O.OP_EQ, O.OP_LT, O.OP_LE, O.OP_GT, O.OP_GE):
+            for sem in (O.SEM_REFERENCE, O.SEM_SQL):
+                got = words(capi.plain_pred(d_page, n, t, op, lit, sem))
+                assert np.array_equal(got, O.plain_pred(page, n, t, op, lit, sem)), (type_name, n, op, sem)
+        lst = np.array([vals[0], vals[-1], 499]).astype(npt)
+        got = words(capi.plain_pred(d_page, n, t, O.OP_IN, lst, O.SEM_SQL))
+        assert np.array_equal(got, O.plain_pred(page, n, t, O.OP_IN, lst, O.SEM_SQL))
+    with pytest.raises(capi.IpsError):      # empty reference body, parquet-common.h:252-255
+        capi.plain_pred(d_page, n, t, O.OP_IN, lst, O.SEM_REFERENCE)
+
+
+def test_bitmap_algebra_and_expand(capi, O):
+    rng = np.random.default_rng(7)
+    for n in (1, 64, 65, 1000, 70001):
+        nw = (n + 63) // 64
+        a = rng.integers(0, 2 ** 63, nw).astype(np.uint64) * 2 + rng.integers(0, 2, nw).astype(np.uint64)
+        b = rng.integers(0, 2 ** 63, nw).astype(np.uint64) * 2 + rng.integers(0, 2, nw).astype(np.uint64)
+        tail = n - (nw - 1) * 64
+        if tail < 64:
+            a[-1] &= np.uint64((1 << tail) - 1)
+            b[-1] &= np.uint64((1 << tail) - 1)
+        assert np.array_equal(words(capi.bitmap_and(dev_words(a), dev_words(b), n)), a & b)
+        assert np.array_equal(words(capi.bitmap_or(dev_words(a), dev_words(b), n)), a | b)
+        assert capi.bitmap_count(dev_words(a), n) == int(bits_of(a, n).sum())
+        ones = words(capi.bitmap_fill(dev_words(a), n, 1))
+        assert bits_of(ones, n).all() and (tail == 64 or int(ones[-1]) >> tail == 0)
+        assert not words(capi.bitmap_fill(dev_words(a), n, 0)).any()
+        # IntersectBitset (hdfs-parquet-scanner.cc:326-331)
+        k = int(bits_of(a, n).sum())
+        sub_bits = rng.random(max(k, 1)) < 0.4
+        sub = np.packbits(sub_bits, bitorder="little")
+        sub = np.concatenate([sub, np.zeros(-len(sub) % 8, np.uint8)]).view(np.uint64)
+        got = words(capi.bitmap_expand(dev_words(a), dev_words(sub), n))
+        assert np.array_equal(got, O.bitmap_expand(a, sub, n)), n
+
+
+def test_nullable_dictionary_column(capi, O):
+    """ColumnReader::Lt on an OPTIONAL dictionary column (hdfs-parquet-scanner.cc:352-369):
+    nonnull = def_levels.Eq(max_def); data = dict.Lt over count(nonnull) values; IntersectBitset."""
+    rng = np.random.default_rng(17)
+    n = 30011
+    is_set = rng.random(n) < 0.8
+    data_vals = rng.integers(-1000, 1000, int(is_set.sum())).astype(np.int32)
+    defs = O.fle_encode(is_set.astype(np.uint32), 1)        # FLE def levels, bw = Log2(1+1) = 1
+    d, dict_page, codes = O.dict_build(data_vals, O.T_INT32)
+    bw, blocks = page_blocks(O.dict_write_data(codes, len(d)))
+    dd = capi.Dict(dict_page, O.T_INT32)
+    nonnull = capi.fle_pred(dev_words(defs), n, 1, O.OP_EQ, 1)
+    k = capi.bitmap_count(nonnull, n)
+    assert k == len(data_vals)
+    data_bm = dd.pred(dev_words(blocks), k, bw, O.OP_LT, np.int32(-200))
+    got = bits_of(words(capi.bitmap_expand(nonnull, data_bm, n)), n)
+    expect = np.zeros(n, bool)
+    expect[np.flatnonzero(is_set)[data_vals < -200]] = True
+    assert np.array_equal(got, expect)
+    dd.close()
+
+
+def test_fused_program(capi, O):
+    """EvalSimplePredicates over several columns in one launch vs node-by-node oracle evaluation:
+    BETWEEN = And(Ge, Le); And(Gt a, Lt b); Or; IN; PLAIN leaves (int32, int64, double)."""
+    rng = np.random.default_rng(23)
+    for n in (1, 2047, 2049, 50021):
+        c0 = rng.integers(0, 1 << 12, n).astype(np.uint32)
+        c1 = rng.integers(0, 1 << 4, n).astype(np.uint32)
+        c2 = rng.integers(0, 1 << 21, n).astype(np.uint32)
+        p32 = rng.integers(-1000, 1000, n).astype(np.int32)
+        p64 = rng.integers(-10 ** 12, 10 ** 12, n).astype(np.int64)
+        pf64 = rng.normal(0, 10, n)
+        e0, e1, e2 = O.fle_encode(c0, 12), O.fle_encode(c1, 4), O.fle_encode(c2, 21)
+        pad = np.zeros(16, np.uint8)
+        d32 = torch.from_numpy(np.concatenate([p32.view(np.uint8), pad])).cuda()
+        d64 = torch.from_numpy(np.concatenate([p64.view(np.uint8), pad])).cuda()
+        df64 = torch.from_numpy(np.concatenate([pf64.view(np.uint8), pad])).cuda()
+        de0, de1, de2 = dev_words(e0), dev_words(e1), dev_words(e2)
+        cols = [capi.fle_column(de0, 12), capi.fle_column(de1, 4), capi.fle_column(de2, 21),
+                capi.plain_column(d32, O.T_INT32), capi.plain_column(d64, O.T_INT64),
+                capi.plain_column(df64, O.T_DOUBLE)]
+        L, PL, AND, OR = capi.leaf, capi.plain_leaf, capi.and_node, capi.or_node
+        # Q6-shaped: c0 >= 1000 AND c0 < 3000 AND (c1 BETWEEN 5 AND 7) AND c2 < 2^20
+        nodes = [L(0, O.OP_GE, 1000), L(0, O.OP_LT, 3000), AND(),
+                 L(1, O.OP_GE, 5), L(1, O.OP_LE, 7), AND(), AND(),
+                 L(2, O.OP_LT, 1 << 20), AND()]
+        got = bits_of(words(capi.eval_program(nodes, cols, n)), n)
+        exp = (c0 >= 1000) & (c0 < 3000) & (c1 >= 5) & (c1 <= 7) & (c2 < (1 << 20))
+        assert np.array_equal(got, exp), n
+        # mixed encodings with OR and IN
+        nodes = [PL(3, O.OP_GT, np.int32(100), O.T_INT32), PL(4, O.OP_LE, np.int64(0), O.T_INT64), OR(),
+                 L(1, O.OP_IN, [1, 9, 15]), AND(),
+                 PL(5, O.OP_LT, np.float64(-3.5), O.T_DOUBLE), OR()]
+        got = bits_of(words(capi.eval_program(nodes, cols, n)), n)
+        exp = (((p32 > 100) | (p64 <= 0)) & np.isin(c1, [1, 9, 15])) | (pf64 < -3.5)
+        assert np.array_equal(got, exp), n
+        # a single leaf equals ips_fle_pred
+        nodes = [L(2, O.OP_EQ, int(c2[0]))]
+        assert np.array_equal(words(capi.eval_program(nodes, cols, n)),
+                              O.fle_pred(e2, n, 21, O.OP_EQ, int(c2[0])))
+    with pytest.raises(capi.IpsError):
+        capi.eval_program([capi.and_node()], cols, n)            # stack underflow is an error
