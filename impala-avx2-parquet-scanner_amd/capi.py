@@ -13,7 +13,7 @@ import numpy as np
 import torch  # noqa: F401  (load torch's HIP runtime first)
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "libips_hip.so")
+LIB_PATH = os.environ.get("IPS_LIB") or os.path.join(_DIR, "libips_hip.so")  # IPS_LIB: dev builds
 
 OP_EQ, OP_LT, OP_LE, OP_GT, OP_GE, OP_IN = range(6)
 T_INT8, T_INT16, T_INT32, T_INT64, T_FLOAT, T_DOUBLE = range(6)

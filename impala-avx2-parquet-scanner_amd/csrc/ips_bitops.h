@@ -29,9 +29,9 @@ struct CmpState {
 // One plane step.  x = this lane's 32 bits of plane i, c = all-ones if bit i of the constant is
 // set else zero (wave-uniform).
 IPS_HD void cmp_step(CmpState& s, uint32_t x, uint32_t c) {
-  uint32_t t = x ^ c;          // bit differs from the constant
-  s.lt |= s.eq & c & t;        // constant has 1, value has 0, equal so far
-  s.eq &= ~t;
+  uint32_t below = ~x & c;     // constant has 1, value has 0           (one bit-select)
+  s.lt |= s.eq & below;        // ... and equal so far                   (one and-or)
+  s.eq &= ~(x ^ c);            // still equal after this plane           (one 3-input bitop)
 }
 
 // Final selection for Eq/Lt/Le/Gt/Ge from (lt, eq): sel_lt/sel_eq pick the terms, inv flips.

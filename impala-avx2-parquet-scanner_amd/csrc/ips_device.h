@@ -195,37 +195,80 @@ __device__ __forceinline__ uint32_t finish_bitmap_dword(uint32_t sel_msb_first, 
 // Number of bitmap dwords that exist: 2 * ceil(n/64).
 __device__ __forceinline__ int64_t bitmap_dwords(int64_t n_rows) { return 2 * ((n_rows + 63) / 64); }
 
-// ---- in-place, order-preserving compaction of a row tile held in LDS -------------------------
-// lds32 holds the 2048 values of the sub-tile in the padded row layout; bm = this lane's bitmap
-// dword (lane 2i, 2i+1 = low, high dword of block i's word).  Afterwards lds32[0..count) holds
-// the selected values in row order (linear layout).  Returns count (wave-uniform).
-__device__ __forceinline__ uint32_t compact_row_tile(uint32_t* lds32, uint32_t bm, int lane) {
-  uint32_t vals[32];
-  const int lane_dw = (lane >> 5) * kRowTileStrideDw + (lane & 31);
-#pragma unroll
-  for (int i = 0; i < 32; ++i) vals[i] = lds32[2 * i * kRowTileStrideDw + lane_dw];
-  wave_lds_fence();  // every read of the row tile is done before any compacted write lands
-  uint32_t run = 0;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    uint32_t m_lo = __builtin_amdgcn_readlane(bm, 2 * i);
-    uint32_t m_hi = __builtin_amdgcn_readlane(bm, 2 * i + 1);
-    uint32_t pos = run + __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
-    uint64_t m = ((uint64_t)m_hi << 32) | m_lo;
-    if ((m >> lane) & 1ull) lds32[pos] = vals[i];
-    run += __builtin_popcount(m_lo) + __builtin_popcount(m_hi);
-  }
-  return run;
+// ---- order-preserving compaction of the selected rows of a sub-tile -------------------------
+// Wave-wide inclusive prefix sum in 6 DPP adds (row_shr 1,2,4,8 inside each 16-lane row, then
+// row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3).
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);  // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);  // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false); // row_bcast:15
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false); // row_bcast:31
+  return x;
 }
 
-// lds32[0..count) -> dst[0..count), coalesced; dst is 16-byte aligned.
+// Two LDS images of the compacted sub-tile, chosen per sub-tile by its (wave-uniform) count:
+//  - sparse (count <= kSparseMax): element P at dword P.  Few lanes are active per step, so bank
+//    conflicts are rare and the address is a running pointer.
+//  - dense: element P at dword P + P/32.  The one-dword pad per 32 elements keeps the per-lane
+//    scatter conflict-free up to 100 % selectivity (lane l writes element 32*l + j in step j:
+//    bank (j + l) mod 32).
+#ifndef IPS_SPARSE_VARIANT
+#define IPS_SPARSE_VARIANT 0
+#endif
+constexpr uint32_t kSparseMax = 320;  // 15.6 % of 2048 rows
+__device__ __forceinline__ uint32_t compact_dw(uint32_t P, bool dense) {
+  return dense ? P + (P >> 5) : P;
+}
+
+// Each lane appends the selected ones of its own 32 rows (v[j] <-> bit j of bm) behind those of
+// all lower lanes: no cross-lane traffic besides the prefix sum.  Returns the sub-tile's count.
+// The caller fences before (the region still holds the planes) and after.
+__device__ __forceinline__ uint32_t compact_lane_values(uint32_t* lds32, uint32_t bm,
+                                                        const uint32_t (&v)[32]) {
+  const uint32_t mine = (uint32_t)__builtin_popcount(bm);
+  const uint32_t incl = wave_inclusive_scan(mine);
+  const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+  uint32_t P = incl - mine;
+  if (total <= kSparseMax) {
+#if IPS_SPARSE_VARIANT == 1
+    // position from a popcount inside the branch: steps in which no lane selects row j are
+    // skipped whole (s_cbranch_execz), which is most steps below ~2 % selectivity
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      if (bm & (1u << j)) lds32[P + (uint32_t)__builtin_popcount(bm & ((1u << j) - 1u))] = v[j];
+    }
+#else
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const bool sel = (bm & (1u << j)) != 0u;
+      if (sel) lds32[P] = v[j];
+      P += sel ? 1u : 0u;
+    }
+#endif
+  } else {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const bool sel = (bm & (1u << j)) != 0u;
+      if (sel) lds32[P + (P >> 5)] = v[j];
+      P += sel ? 1u : 0u;
+    }
+  }
+  return total;
+}
+
+// compacted LDS image [0, count) -> dst[0, count), coalesced 16-byte stores; dst 16-byte aligned.
 __device__ __forceinline__ void store_compacted(const uint32_t* lds32, uint32_t count,
                                                 uint32_t* __restrict__ dst, int lane) {
+  const bool dense = count > kSparseMax;
   for (uint32_t p = 4u * lane; p < count; p += 4u * kWave) {
+    const uint32_t* src = lds32 + compact_dw(p, dense);  // 4 elements never straddle a pad
     if (p + 4 <= count) {
-      *reinterpret_cast<u32x4*>(dst + p) = *reinterpret_cast<const u32x4*>(lds32 + p);
+      u32x4 t = {src[0], src[1], src[2], src[3]};
+      *reinterpret_cast<u32x4*>(dst + p) = t;
     } else {
-      for (uint32_t e = p; e < count; ++e) dst[e] = lds32[e];
+      for (uint32_t e = p; e < count; ++e) dst[e] = src[e - p];
     }
   }
 }

@@ -71,10 +71,8 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kerne
     if (__builtin_amdgcn_ballot_w64(bm != 0u) != 0ull) {  // wave-uniform: any row selected
       uint32_t v[32];
       planes_to_values<W>(p, v);
-      wave_lds_fence();  // all plane reads precede the row-tile overwrite of the same region
-      values_to_row_tile(lds32, lane, v);
-      wave_lds_fence();
-      count = compact_row_tile(lds32, bm, lane);
+      wave_lds_fence();  // all plane reads precede the overwrite of the same LDS region
+      count = compact_lane_values(lds32, bm, v);
       wave_lds_fence();
       if (G == 0) {
         store_compacted(lds32, count, reinterpret_cast<uint32_t*>(batch_values) +
@@ -83,7 +81,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kerne
         typename GatherT<G>::type* dst = batch_values + tile * kRowsPerTile;
         int bad = 0;
         for (uint32_t e = lane; e < count; e += kWave) {
-          uint32_t code = lds32[e];
+          uint32_t code = lds32[compact_dw(e, count > kSparseMax)];
           if (code < dict_entries) dst[e] = dict[code]; else bad = 1;
         }
         if (bad && bad_index) *bad_index = 1;

@@ -30,6 +30,7 @@ ips_status hip_fail(hipError_t e, const char* what);
 // at the kernel's occupancy, never more than the work.  Occupancy is queried once per kernel.
 int grid_for_tiles(const void* kernel, int64_t tiles);
 int device_cus();
+int grid_mult();
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

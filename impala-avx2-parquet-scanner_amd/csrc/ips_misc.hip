@@ -43,7 +43,7 @@ ips_status launch_fle_pred(int w, const uint64_t* enc, int64_t n_rows, const Pre
   const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   // LDS (4 * 256*(w|1) bytes per block) and VGPRs allow >= 4 blocks per CU for every w
   int64_t want = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-  int64_t cap = (int64_t)device_cus() * 4;
+  int64_t cap = (int64_t)device_cus() * 4 * grid_mult();
   int grid = (int)(want < cap ? want : cap);
   if (grid <= 0) return IPS_ERR_HIP;
   size_t lds = (size_t)kWavesPerBlock * plane_tile_bytes(w);
