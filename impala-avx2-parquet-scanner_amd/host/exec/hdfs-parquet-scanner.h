@@ -1,0 +1,350 @@
+// exec/hdfs-parquet-scanner.h (MI355X facade) -- the slice of HdfsParquetScanner that sits on the
+// hot path (hdfs-parquet-scanner.h:91-102, .cc:305-567, 1006-1038, 1078-1182, 1825-1907):
+//   Eq/Lt/Le/Gt/Ge/In<T>(col_idx, num_rows, bitset, literal)   -> ColumnReader<T> dispatch
+//   CreateSimplePredicates / EvalSimplePredicates               1024-row batches, conjunct AND
+//   bitmap -> skip list, ReadValue(skip) / SkipValue            late materialisation
+// Everything the reference obtains from the absent Impala runtime (footer, thrift page headers,
+// DiskIoMgr streams, decompression, tuples) is replaced by AddDictionaryColumn / AddPlainColumn,
+// which take the uncompressed page payloads exactly as ReadDataPage would hand them to
+// InitDataPage (.cc:882-916): [int32 n_def_bytes][FLE def levels] (OPTIONAL columns only) followed
+// by [uint8 code_width][FLE codes] or PLAIN values.
+#pragma once
+#include <string.h>
+
+#include <memory>
+#include <type_traits>
+#include <vector>
+
+#include "../exprs/simple-predicates.h"
+#include "../util/dict-encoding.h"
+#include "parquet-common.h"
+
+namespace impala {
+
+class HdfsParquetScanner {
+ public:
+  class BaseColumnReader {
+   public:
+    virtual ~BaseColumnReader() {}
+    virtual bool SkipValue(int skip_rows) = 0;
+    virtual bool LowerLeaf(int op, const void* lits, int n_lits, ips_column* col, ips_node* node) = 0;
+    int64_t num_buffered_values() const { return num_buffered_values_; }
+    void consume(int64_t n) { num_buffered_values_ -= n; }
+    int max_def_level() const { return max_def_level_; }
+   protected:
+    int64_t num_buffered_values_ = 0;
+    int max_def_level_ = 0;
+  };
+
+  // Per column type reader, hdfs-parquet-scanner.cc:305-567
+  template <typename T>
+  class ColumnReader : public BaseColumnReader {
+   public:
+    // ColumnReader::IntersectBitset, .cc:326-331 (the device twin is ips_bitmap_expand)
+    static void IntersectBitset(SkipBitset& root_bitset, SkipBitset& sub_bitset) {
+      int64_t j = -1;
+      for (size_t i = 0; i < root_bitset.size(); ++i)
+        if (root_bitset[i]) root_bitset.set(i, sub_bitset[(size_t)++j]);
+    }
+
+    // one body for Eq..In (.cc:333-445): dictionary pages go through DictDecoder<T>, nullable
+    // ones through def_levels->Eq(max_def) + IntersectBitset; PLAIN pages through the encoder
+    template <typename L>
+    void Pred(int op, int64_t num_rows, SkipBitset& skip_bitset, L& lit) {
+      if (dict_decoder_) {
+        if (max_def_level_ == 0) { Call(op, *dict_decoder_, num_rows, skip_bitset, lit); return; }
+        fle_def_levels_->Eq(num_rows, skip_bitset, (uint64_t)max_def_level_);
+        SkipBitset data_bitset;
+        Call(op, *dict_decoder_, (int64_t)skip_bitset.count(), data_bitset, lit);
+        IntersectBitset(skip_bitset, data_bitset);
+      } else {
+        PlainCall(op, num_rows, skip_bitset, lit);
+      }
+    }
+
+    // ReadValue(pool, tuple, skip_rows) -> ReadSlot(skip) (.cc:1006-1027, 515-531).  *is_null
+    // is set for a NULL row of an OPTIONAL column (ReadDefinitionLevel, .cc:927-979).
+    bool ReadValue(T* slot, int skip_rows, bool* is_null = nullptr) {
+      if (is_null) *is_null = false;
+      if (max_def_level_ > 0) {
+        int data_skip = 0;
+        for (int i = 0; i < skip_rows; ++i) {
+          int def;
+          if (!fle_def_levels_->Get(&def)) return false;
+          if (def == max_def_level_) ++data_skip;
+        }
+        int def;
+        if (!fle_def_levels_->Get(&def)) return false;
+        if (def != max_def_level_) {
+          if (is_null) *is_null = true;
+          return data_skip == 0 || SkipData(data_skip);
+        }
+        return ReadData(slot, data_skip);
+      }
+      return ReadData(slot, skip_rows);
+    }
+
+    virtual bool SkipValue(int skip_rows) {  // .cc:1029-1038, 533-547
+      if (max_def_level_ > 0) {
+        int data_skip = 0;
+        for (int i = 0; i < skip_rows; ++i) {
+          int def;
+          if (!fle_def_levels_->Get(&def)) return false;
+          if (def == max_def_level_) ++data_skip;
+        }
+        return data_skip == 0 || SkipData(data_skip);
+      }
+      return SkipData(skip_rows);
+    }
+
+    virtual bool LowerLeaf(int op, const void* lits, int n_lits, ips_column* col, ips_node* node) {
+      memset(col, 0, sizeof(*col));
+      memset(node, 0, sizeof(*node));
+      node->kind = IPS_NODE_LEAF;
+      if (max_def_level_ > 0 || n_lits > 16) return false;  // nullable columns: node-by-node path
+      if (dict_decoder_) {
+        ips_xl_kind kind; ips_op fle_op; int n_codes = 0;
+        uint64_t codes[16];
+        if (ips_dict_translate(dict_decoder_->handle(), (ips_op)op, lits, n_lits, &kind, &fle_op,
+                               codes, &n_codes) != IPS_OK)
+          return false;
+        col->encoding = IPS_COL_FLE;
+        col->bit_width = dict_decoder_->code_bit_width();
+        col->d_data = dict_decoder_->codes()->device_blocks();
+        // constant answers become range predicates that are always false / true on codes
+        if (kind == IPS_XL_ALL_FALSE) { node->op = IPS_OP_LT; node->n_consts = 1; node->consts[0] = 0; return true; }
+        if (kind == IPS_XL_ALL_TRUE) { node->op = IPS_OP_GE; node->n_consts = 1; node->consts[0] = 0; return true; }
+        node->op = fle_op;
+        node->n_consts = n_codes;
+        for (int i = 0; i < n_codes; ++i) node->consts[i] = codes[i];
+        return true;
+      }
+      col->encoding = IPS_COL_PLAIN;
+      col->type = IpsTypeOf<T>::value;
+      if (!plain_dev_.get() && !plain_dev_.upload(plain_begin_, (size_t)plain_rows_ * ips_plain_stride(IpsTypeOf<T>::value)))
+        return false;
+      col->d_data = plain_dev_.get();
+      if (IPS_PLAIN_SEMANTICS == IPS_SEM_REFERENCE) {  // literal OP x == x OP' literal (quirk Q1)
+        if (op == IPS_OP_LT) op = IPS_OP_GT; else if (op == IPS_OP_GT) op = IPS_OP_LT;
+        else if (op == IPS_OP_LE) op = IPS_OP_GE; else if (op == IPS_OP_GE) op = IPS_OP_LE;
+        else if (op == IPS_OP_IN) return false;  // no reference behaviour (empty body)
+      }
+      node->op = op;
+      node->n_consts = n_lits;
+      for (int i = 0; i < n_lits; ++i) memcpy(&node->consts[i], (const T*)lits + i, sizeof(T));
+      return true;
+    }
+
+   private:
+    friend class HdfsParquetScanner;
+    template <typename D, typename L>
+    static void Call(int op, D& d, int64_t n, SkipBitset& b, L& lit);
+    template <typename L>
+    void PlainCall(int op, int64_t n, SkipBitset& b, L& lit);
+
+    bool ReadData(T* slot, int skip) {
+      if (dict_decoder_) return dict_decoder_->GetValue(slot, skip);
+      data_ += ParquetPlainEncoder::Decode(data_, -1, slot, skip);
+      return data_ <= data_end_;
+    }
+    bool SkipData(int skip) {
+      if (dict_decoder_) return dict_decoder_->SkipValue(skip);
+      T dummy;
+      data_ += ParquetPlainEncoder::Skip(data_, -1, &dummy, skip);
+      return data_ <= data_end_;
+    }
+
+    std::unique_ptr<DictDecoder<T>> dict_decoder_;
+    std::unique_ptr<FleDecoder> fle_def_levels_;
+    uint8_t* data_ = nullptr;        // PLAIN: current position (the predicates start here)
+    uint8_t* data_end_ = nullptr;
+    uint8_t* plain_begin_ = nullptr;
+    int64_t plain_rows_ = 0;
+    ips::DeviceBuffer plain_dev_;
+  };
+
+  HdfsParquetScanner() {}
+  ~HdfsParquetScanner() { for (SimplePredicate* p : owned_) delete p; }
+
+  // ---- page plumbing (stands in for ReadDataPage / InitDataPage) ----
+  // data_page: [int32 n_def_bytes][def levels]? [uint8 width][codes]; max_def_level 0 = REQUIRED
+  template <typename T>
+  int AddDictionaryColumn(uint8_t* dict_page, int dict_len, uint8_t* data_page, int data_len,
+                          int64_t num_values, int max_def_level = 0) {
+    auto* r = new ColumnReader<T>();
+    r->num_buffered_values_ = num_values;
+    r->max_def_level_ = max_def_level;
+    uint8_t* p = data_page;
+    int left = data_len;
+    if (max_def_level > 0) {  // .cc:882-901
+      int32_t n_def_bytes;
+      memcpy(&n_def_bytes, p, 4);
+      p += 4; left -= 4;
+      r->fle_def_levels_.reset(new FleDecoder(p, n_def_bytes, BitUtil::Log2((uint64_t)max_def_level + 1)));
+      p += n_def_bytes; left -= n_def_bytes;
+    }
+    r->dict_decoder_.reset(new DictDecoder<T>(dict_page, dict_len, -1));
+    r->dict_decoder_->SetData(p, left);
+    column_readers_.emplace_back(r);
+    return (int)column_readers_.size() - 1;
+  }
+
+  template <typename T>
+  int AddPlainColumn(uint8_t* page, int64_t num_values) {
+    auto* r = new ColumnReader<T>();
+    r->num_buffered_values_ = num_values;
+    r->data_ = r->plain_begin_ = page;
+    r->plain_rows_ = num_values;
+    T dummy;
+    r->data_end_ = page + num_values * ParquetPlainEncoder::ByteSize(dummy);
+    column_readers_.emplace_back(r);
+    return (int)column_readers_.size() - 1;
+  }
+
+  // ---- hdfs-parquet-scanner.h:91-102 ----
+  template <typename T> void Eq(int idx, int64_t n, SkipBitset& b, T& val) { reader<T>(idx)->Pred(IPS_OP_EQ, n, b, val); }
+  template <typename T> void Lt(int idx, int64_t n, SkipBitset& b, T& val) { reader<T>(idx)->Pred(IPS_OP_LT, n, b, val); }
+  template <typename T> void Le(int idx, int64_t n, SkipBitset& b, T& val) { reader<T>(idx)->Pred(IPS_OP_LE, n, b, val); }
+  template <typename T> void Gt(int idx, int64_t n, SkipBitset& b, T& val) { reader<T>(idx)->Pred(IPS_OP_GT, n, b, val); }
+  template <typename T> void Ge(int idx, int64_t n, SkipBitset& b, T& val) { reader<T>(idx)->Pred(IPS_OP_GE, n, b, val); }
+  template <typename T> void In(int idx, int64_t n, SkipBitset& b, std::vector<T>& val) { reader<T>(idx)->Pred(IPS_OP_IN, n, b, val); }
+
+  // conjunct list, .cc:1825-1835.  Nodes live as long as the scanner: every node is handed to
+  // Own() once (RuntimeState::obj_pool() in the reference, scalar-fn-call.cc:947).
+  void AddSimplePredicate(SimplePredicate* root) { if (root) simple_predicates_.push_back(root); }
+  void ClearSimplePredicates() { simple_predicates_.clear(); }
+  SimplePredicate* Own(SimplePredicate* p) { owned_.push_back(p); return p; }
+  size_t num_simple_predicates() const { return simple_predicates_.size(); }
+
+  // .cc:1837-1865: batch = min(1024, rows left in every column's page); AND over the conjuncts
+  bool EvalSimplePredicates(SkipBitset& skip_bitset) {
+    int64_t limit_rows = 1024;
+    for (auto& c : column_readers_) {
+      if (c->num_buffered_values() == 0) return false;  // the reference would read the next page
+      if (c->num_buffered_values() < limit_rows) limit_rows = c->num_buffered_values();
+    }
+    for (auto& c : column_readers_) c->consume(limit_rows);
+    simple_predicates_[0]->GetBitset(this, limit_rows, skip_bitset);
+    for (size_t i = 1; i < simple_predicates_.size(); ++i) {
+      SkipBitset tmp_bitset;
+      simple_predicates_[i]->GetBitset(this, limit_rows, tmp_bitset);
+      skip_bitset &= tmp_bitset;
+    }
+    return ips::sticky_status() == IPS_OK && (int64_t)skip_bitset.size() == limit_rows;
+  }
+
+  // bitmap -> skip list, .cc:1134-1148: skip_rows[j] = zeros before the j-th set bit
+  static void BitsetToSkipList(const SkipBitset& skip_bitset, std::vector<int>* skip_rows,
+                               int* last_skip_rows) {
+    skip_rows->clear();
+    int start = 0;
+    const int n = (int)skip_bitset.size();
+    for (int i = 0; i < n; ++i)
+      if (skip_bitset[(size_t)i]) { skip_rows->push_back(i - start); start = i + 1; }
+    *last_skip_rows = n - start;
+  }
+
+  template <typename T>
+  bool ReadValue(int idx, T* slot, int skip_rows, bool* is_null = nullptr) {
+    return reader<T>(idx)->ReadValue(slot, skip_rows, is_null);
+  }
+  bool SkipValue(int idx, int skip_rows) { return column_readers_[(size_t)idx]->SkipValue(skip_rows); }
+
+  // facade extra: the whole conjunct list over all rows of the pages in one ips_eval_program
+  // launch (REQUIRED columns only).  bitmap_words: ceil(num_rows/64) LSB-first words.
+  bool EvalSimplePredicatesFused(int64_t num_rows, std::vector<uint64_t>* bitmap_words) {
+    lower_cols_.clear();
+    std::vector<ips_node> program;
+    for (size_t i = 0; i < simple_predicates_.size(); ++i) {
+      if (!simple_predicates_[i]->Lower(this, &program)) return false;
+      if (i > 0) { ips_node n; memset(&n, 0, sizeof(n)); n.kind = IPS_NODE_AND; program.push_back(n); }
+    }
+    bitmap_words->assign((size_t)((num_rows + 63) / 64), 0);
+    ips::DeviceBuffer bm(bitmap_words->size() * 8);
+    return ips::ok(ips_eval_program(program.data(), (int)program.size(), lower_cols_.data(),
+                                    (int)lower_cols_.size(), num_rows, bm.as<uint64_t>(), nullptr),
+                   "ips_eval_program") &&
+           bm.download(bitmap_words->data(), bitmap_words->size() * 8);
+  }
+
+  // used by LeafOperate::Lower: returns the column slot of the program for reader idx
+  bool LowerLeaf(int idx, int op, const void* lits, int n_lits, ips_node* node) {
+    if (lower_cols_.size() >= IPS_PROGRAM_MAX_COLS) return false;
+    ips_column col;
+    if (!column_readers_[(size_t)idx]->LowerLeaf(op, lits, n_lits, &col, node)) return false;
+    for (size_t i = 0; i < lower_cols_.size(); ++i)
+      if (lower_cols_[i].d_data == col.d_data) { node->column = (int)i; return true; }
+    lower_cols_.push_back(col);
+    node->column = (int)lower_cols_.size() - 1;
+    return true;
+  }
+
+  ips_status parse_status() const { return ips::sticky_status(); }
+
+ private:
+  // the reference reinterpret_casts on the literal's type (.cc:1870, quirk Q9); the facade
+  // requires the column to have been added with the same T
+  template <typename T>
+  ColumnReader<T>* reader(int idx) { return static_cast<ColumnReader<T>*>(column_readers_[(size_t)idx].get()); }
+
+  std::vector<std::unique_ptr<BaseColumnReader>> column_readers_;
+  std::vector<SimplePredicate*> simple_predicates_;
+  std::vector<SimplePredicate*> owned_;
+  std::vector<ips_column> lower_cols_;
+};
+
+// ---- ColumnReader dispatch helpers ----
+template <typename T>
+template <typename D, typename L>
+void HdfsParquetScanner::ColumnReader<T>::Call(int op, D& d, int64_t n, SkipBitset& b, L& lit) {
+  if constexpr (std::is_same<L, std::vector<T>>::value) {
+    d.In(n, b, lit);
+  } else {
+    switch (op) {
+      case IPS_OP_EQ: d.Eq(n, b, lit); break;
+      case IPS_OP_LT: d.Lt(n, b, lit); break;
+      case IPS_OP_LE: d.Le(n, b, lit); break;
+      case IPS_OP_GT: d.Gt(n, b, lit); break;
+      default: d.Ge(n, b, lit); break;
+    }
+  }
+}
+
+template <typename T>
+template <typename L>
+void HdfsParquetScanner::ColumnReader<T>::PlainCall(int op, int64_t n, SkipBitset& b, L& lit) {
+  if constexpr (std::is_same<L, std::vector<T>>::value) {
+    ParquetPlainEncoder::In<T>(data_, -1, n, b, lit);
+  } else {
+    switch (op) {
+      case IPS_OP_EQ: ParquetPlainEncoder::Eq<T>(data_, -1, n, b, lit); break;
+      case IPS_OP_LT: ParquetPlainEncoder::Lt<T>(data_, -1, n, b, lit); break;
+      case IPS_OP_LE: ParquetPlainEncoder::Le<T>(data_, -1, n, b, lit); break;
+      case IPS_OP_GT: ParquetPlainEncoder::Gt<T>(data_, -1, n, b, lit); break;
+      default: ParquetPlainEncoder::Ge<T>(data_, -1, n, b, lit); break;
+    }
+  }
+}
+
+// ---- leaves of the predicate tree, simple-predicates.h:165-205 ----
+template <typename T, int OP>
+void LeafOperate<T, OP>::GetBitset(HdfsParquetScanner* scanner, int64_t num_rows, SkipBitset& skip_bitset) {
+  switch (OP) {
+    case IPS_OP_EQ: scanner->Eq(idx_, num_rows, skip_bitset, vals_[0]); break;
+    case IPS_OP_LT: scanner->Lt(idx_, num_rows, skip_bitset, vals_[0]); break;
+    case IPS_OP_LE: scanner->Le(idx_, num_rows, skip_bitset, vals_[0]); break;
+    case IPS_OP_GT: scanner->Gt(idx_, num_rows, skip_bitset, vals_[0]); break;
+    case IPS_OP_GE: scanner->Ge(idx_, num_rows, skip_bitset, vals_[0]); break;
+    default: scanner->In(idx_, num_rows, skip_bitset, vals_); break;
+  }
+}
+
+template <typename T, int OP>
+bool LeafOperate<T, OP>::Lower(HdfsParquetScanner* scanner, std::vector<ips_node>* program) {
+  ips_node n;
+  if (!scanner->LowerLeaf(idx_, OP, vals_.data(), (int)vals_.size(), &n)) return false;
+  program->push_back(n);
+  return true;
+}
+
+}  // namespace impala

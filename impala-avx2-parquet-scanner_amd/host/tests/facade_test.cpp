@@ -1,0 +1,361 @@
+// facade_test.cpp -- exercises the C++ facade (reference class names over the C-ABI) the way the
+// reference's own tests do: ValidateFle of fle-test.cc:172-200, ValidateDict of
+// dict-test.cc:32-62, plus the predicate / scanner paths the reference never tests, against a
+// row-at-a-time model.  Needs a GPU (everything runs through libips_hip.so).
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <set>
+#include <vector>
+
+#include "../exprs/scalar-fn-call.h"
+
+using namespace impala;
+
+static int g_fail = 0, g_checks = 0;
+#define CHECK(cond)                                                          \
+  do {                                                                       \
+    ++g_checks;                                                              \
+    if (!(cond)) {                                                           \
+      if (++g_fail <= 20) fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+    }                                                                        \
+  } while (0)
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint64_t rnd() {
+  uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// ---- fle-test.cc:172-200 -------------------------------------------------------------------
+static void ValidateFle(const std::vector<int>& values, int bit_width, int expected_len) {
+  const int len = 64 * 1024;
+  std::vector<uint8_t> buffer(len);
+  FleEncoder encoder(buffer.data(), len, bit_width);
+  for (size_t i = 0; i < values.size(); ++i) CHECK(encoder.Put((uint64_t)values[i]));
+  int encoded_len = encoder.Flush();
+  if (expected_len != -1) CHECK(encoded_len == expected_len);
+  FleDecoder decoder(buffer.data(), encoded_len, bit_width);
+  for (size_t i = 0; i < values.size(); ++i) {
+    uint64_t val;
+    bool result = decoder.Get(&val);
+    CHECK(result);
+    CHECK((uint64_t)values[i] == val);
+  }
+}
+
+static void TestFleSpecificSequences() {
+  std::vector<int> values(100);
+  for (int i = 0; i < 50; ++i) values[i] = 0;
+  for (int i = 50; i < 100; ++i) values[i] = 1;
+  ValidateFle(values, 1, 16);
+  ValidateFle(values, 2, 32);
+  for (int width = 2; width <= 32; ++width) ValidateFle(values, width, -1);
+  for (int i = 0; i < 100; ++i) values[i] = i % 2;
+  ValidateFle(values, 1, 16);
+  for (int width = 2; width <= 32; ++width) ValidateFle(values, width, -1);
+}
+
+static void TestFleValues() {
+  for (int width = 1; width <= 32; ++width) {
+    const uint64_t mod = 1ull << width;
+    for (int variant = 0; variant < 4; ++variant) {
+      std::vector<int> values;
+      int n = variant == 0 ? 1 : 1024;
+      for (int v = 0; v < n; ++v)
+        values.push_back(variant == 2 ? 0 : variant == 3 ? 1 : (int)((uint64_t)v % mod));
+      ValidateFle(values, width, -1);
+    }
+    std::vector<int> values;
+    for (int v = 0; v < 1024; ++v) values.push_back((int)(rnd() % mod & 0x7fffffff));
+    ValidateFle(values, width, -1);
+  }
+}
+
+// ---- predicates + cursor (no reference test exists: row model) --------------------------------
+static void TestFlePredicates() {
+  for (int width : {1, 3, 8, 11, 16, 21, 32}) {
+    const uint64_t mod = 1ull << width;
+    const int n = 5000;
+    std::vector<uint32_t> vals(n);
+    std::vector<uint8_t> buffer((size_t)ips_fle_encoded_bytes(n, width));
+    FleEncoder enc(buffer.data(), (int)buffer.size(), width);
+    for (int i = 0; i < n; ++i) { vals[i] = (uint32_t)(rnd() % mod); enc.Put(vals[i]); }
+    int len = enc.Flush();
+    FleDecoder dec(buffer.data(), len, width);
+    uint64_t c = vals[17];
+    // reference-shaped batches of 1024 rows with Skip in between concatenate to the full answer
+    for (int op = 0; op < 5; ++op) {
+      FleDecoder d2(buffer.data(), len, width);
+      int64_t done = 0;
+      while (done < n) {
+        int64_t batch = std::min<int64_t>(1024, n - done);
+        SkipBitset bs;
+        switch (op) {
+          case 0: d2.Eq(batch, bs, c); break;
+          case 1: d2.Lt(batch, bs, c); break;
+          case 2: d2.Le(batch, bs, c); break;
+          case 3: d2.Gt(batch, bs, c); break;
+          default: d2.Ge(batch, bs, c); break;
+        }
+        CHECK((int64_t)bs.size() == batch);
+        for (int64_t i = 0; i < batch; ++i) {
+          uint64_t x = vals[done + i];
+          bool e = op == 0 ? x == c : op == 1 ? x < c : op == 2 ? x <= c : op == 3 ? x > c : x >= c;
+          CHECK(bs[(size_t)i] == e);
+        }
+        done += batch;
+        if (done < n) CHECK(d2.Skip((int)batch));
+      }
+    }
+    // mid-block start + non-advancing + Get(v, skip)
+    uint32_t v;
+    CHECK(dec.Get(&v, 70) && v == vals[70]);
+    CHECK(dec.Get(&v, 0) && v == vals[71]);
+    SkipBitset bs;
+    std::vector<uint64_t> in_list = {vals[100], vals[200], mod - 1};
+    dec.In(300, bs, in_list);
+    for (int i = 0; i < 300; ++i) {
+      uint64_t x = vals[72 + i];
+      CHECK(bs[(size_t)i] == (x == in_list[0] || x == in_list[1] || x == in_list[2]));
+    }
+    CHECK(dec.Get(&v) && v == vals[72]);
+    // end of data
+    FleDecoder d3(buffer.data(), len, width);
+    CHECK(d3.Skip(n - 1));
+    CHECK(d3.Get(&v) && v == vals[n - 1]);
+    CHECK(!d3.Skip(64 * 3));
+  }
+}
+
+// ---- dict-test.cc:32-62, 118-147 ------------------------------------------------------------
+template <typename T>
+static void ValidateDict(const std::vector<T>& values) {
+  std::set<T> values_set(values.begin(), values.end());
+  DictEncoder<T> encoder(nullptr, -1);
+  for (const T& i : values) encoder.Put(i);
+  CHECK(encoder.num_entries() == (int)values_set.size());
+  std::vector<uint8_t> dict_buffer((size_t)encoder.dict_encoded_size() + 8);
+  encoder.WriteDict(dict_buffer.data());
+  std::vector<uint8_t> data_buffer(1 << 20);
+  int data_len = encoder.WriteData(data_buffer.data(), (int)data_buffer.size());
+  CHECK(data_len > 0);
+  encoder.ClearIndices();
+  DictDecoder<T> decoder(dict_buffer.data(), encoder.dict_encoded_size(), -1);
+  decoder.SetData(data_buffer.data(), data_len);
+  for (const T& i : values) {
+    T j;
+    CHECK(decoder.GetValue(&j));
+    CHECK(i == j);
+  }
+}
+
+template <typename T>
+static void TestNumbers(int max_value, int repeat) {
+  std::vector<T> values;
+  for (int val = 0; val < max_value; ++val)
+    for (int i = 0; i < repeat; ++i) values.push_back((T)val);
+  ValidateDict(values);
+}
+
+template <typename T>
+static void TestNumbersAll() {
+  TestNumbers<T>(100, 1);
+  TestNumbers<T>(1, 100);
+  TestNumbers<T>(1, 1);
+  TestNumbers<T>(1, 2);
+}
+
+template <typename T>
+static void TestDictPredicates() {
+  const int n = 6000;
+  std::vector<T> pool;
+  for (int i = 0; i < 300; ++i) pool.push_back((T)((int)(rnd() % 20000) - 10000) + (T)(std::is_floating_point<T>::value ? 0.25 : 0));
+  std::vector<T> vals(n);
+  DictEncoder<T> encoder;
+  for (int i = 0; i < n; ++i) { vals[i] = i < 300 ? pool[i] : pool[rnd() % 300]; encoder.Put(vals[i]); }
+  std::vector<uint8_t> dict_buffer((size_t)encoder.dict_encoded_size() + 8), data_buffer(1 << 20);
+  encoder.WriteDict(dict_buffer.data());
+  int data_len = encoder.WriteData(data_buffer.data(), (int)data_buffer.size());
+  DictDecoder<T> decoder(dict_buffer.data(), encoder.dict_encoded_size(), -1);
+  decoder.SetData(data_buffer.data(), data_len);
+  T lo = *std::min_element(pool.begin(), pool.end()), hi = *std::max_element(pool.begin(), pool.end());
+  std::vector<T> lits = {(T)(lo - 1), lo, pool[5], (T)(pool[5] + (std::is_floating_point<T>::value ? 0.125 : 0)), hi, (T)(hi + 1)};
+  for (T lit : lits) {
+    for (int op = 0; op < 5; ++op) {
+      SkipBitset bs;
+      switch (op) {
+        case 0: decoder.Eq(n, bs, lit); break;
+        case 1: decoder.Lt(n, bs, lit); break;
+        case 2: decoder.Le(n, bs, lit); break;
+        case 3: decoder.Gt(n, bs, lit); break;
+        default: decoder.Ge(n, bs, lit); break;
+      }
+      CHECK((int)bs.size() == n);
+      for (int i = 0; i < n; ++i) {
+        T x = vals[i];
+        bool e = op == 0 ? x == lit : op == 1 ? x < lit : op == 2 ? x <= lit : op == 3 ? x > lit : x >= lit;
+        CHECK(bs[(size_t)i] == e);
+      }
+    }
+  }
+  std::vector<T> in = {pool[1], (T)(hi + 5), pool[250]};
+  SkipBitset bs;
+  decoder.In(n, bs, in);
+  for (int i = 0; i < n; ++i) CHECK(bs[(size_t)i] == (vals[i] == in[0] || vals[i] == in[2]));
+}
+
+// ---- scanner: batches == fused program == row model; nullable; PLAIN; late materialisation ----
+static void TestScanner() {
+  const int n = 10000;
+  std::vector<int32_t> c0(n);
+  std::vector<int64_t> c1(n);
+  std::vector<int32_t> c2(n), c3(n);
+  std::vector<bool> c3_null(n);
+  DictEncoder<int32_t> e0, e3;
+  DictEncoder<int64_t> e1;
+  std::vector<uint32_t> defs;
+  for (int i = 0; i < n; ++i) {
+    c0[i] = (int32_t)(rnd() % 2526);
+    c1[i] = (int64_t)(rnd() % 11) * 1000000007ll;
+    c2[i] = (int32_t)(rnd() % 2000) - 1000;
+    c3_null[i] = (rnd() % 5) == 0;
+    c3[i] = (int32_t)(rnd() % 50);
+    e0.Put(c0[i]); e1.Put(c1[i]);
+    if (!c3_null[i]) e3.Put(c3[i]);
+    defs.push_back(c3_null[i] ? 0u : 1u);
+  }
+  auto pages = [](auto& enc, std::vector<uint8_t>& dict, std::vector<uint8_t>& data) {
+    dict.resize((size_t)enc.dict_encoded_size() + 8);
+    enc.WriteDict(dict.data());
+    data.resize(1 << 20);
+    int len = enc.WriteData(data.data(), (int)data.size());
+    data.resize((size_t)len);
+    return enc.dict_encoded_size();
+  };
+  std::vector<uint8_t> d0, p0, d1, p1, d3, p3;
+  int dl0 = pages(e0, d0, p0), dl1 = pages(e1, d1, p1), dl3 = pages(e3, d3, p3);
+  // OPTIONAL column page: [int32 n_def_bytes][FLE def levels bw=1][uint8 w][codes]
+  std::vector<uint8_t> defbuf((size_t)ips_fle_encoded_bytes(n, 1));
+  FleEncoder defenc(defbuf.data(), (int)defbuf.size(), 1);
+  for (uint32_t d : defs) defenc.Put(d);
+  int32_t n_def_bytes = defenc.Flush();
+  std::vector<uint8_t> p3full(4 + (size_t)n_def_bytes + p3.size());
+  memcpy(p3full.data(), &n_def_bytes, 4);
+  memcpy(p3full.data() + 4, defbuf.data(), (size_t)n_def_bytes);
+  memcpy(p3full.data() + 4 + n_def_bytes, p3.data(), p3.size());
+  std::vector<uint8_t> plain2((size_t)n * 4);
+  memcpy(plain2.data(), c2.data(), plain2.size());
+
+  auto build = [&](HdfsParquetScanner& s, bool with_nullable) {
+    s.AddDictionaryColumn<int32_t>(d0.data(), dl0, p0.data(), (int)p0.size(), n);
+    s.AddDictionaryColumn<int64_t>(d1.data(), dl1, p1.data(), (int)p1.size(), n);
+    s.AddPlainColumn<int32_t>(plain2.data(), n);
+    if (with_nullable) s.AddDictionaryColumn<int32_t>(d3.data(), dl3, p3full.data(), (int)p3full.size(), n, 1);
+  };
+  // conjuncts through the plan-time lowering: c0 >= 300 AND c0 < 1500; c1 IN (..) OR c2 > 500
+  auto conjuncts = [&](std::vector<ExprContext*>& ctxs, bool with_nullable) {
+    ctxs.push_back(new ExprContext(new AndPredicate(
+        new ScalarFnCall("ge", new SlotRef(TYPE_INT, 0), {new Literal(TYPE_INT, (int64_t)300)}),
+        new ScalarFnCall("lt", new Cast(TYPE_INT, new SlotRef(TYPE_INT, 0)), {new Literal(TYPE_INT, (int64_t)1500)}))));
+    ctxs.push_back(new ExprContext(new OrPredicate(
+        new ScalarFnCall("in_set_lookup", new SlotRef(TYPE_BIGINT, 1),
+                         {new Literal(TYPE_BIGINT, (int64_t)(3 * 1000000007ll)), new Literal(TYPE_BIGINT, (int64_t)(7 * 1000000007ll)),
+                          new Literal(TYPE_BIGINT, (int64_t)12345)}),
+        new ScalarFnCall("lt", new SlotRef(TYPE_INT, 2), {new Literal(TYPE_INT, (int64_t)500)}))));
+    if (with_nullable)
+      ctxs.push_back(new ExprContext(new ScalarFnCall("lt", new SlotRef(TYPE_INT, 3), {new Literal(TYPE_INT, (int64_t)24)})));
+  };
+  auto expect = [&](int i, bool with_nullable) {
+    bool a = c0[i] >= 300 && c0[i] < 1500;
+    // PLAIN leaves use the reference operand order (literal OP x): "lt 500" means 500 < x
+    bool b = (c1[i] == 3 * 1000000007ll || c1[i] == 7 * 1000000007ll) || (500 < c2[i]);
+    bool c = !with_nullable || (!c3_null[i] && c3[i] < 24);
+    return a && b && c;
+  };
+
+  for (int with_nullable = 0; with_nullable < 2; ++with_nullable) {
+    HdfsParquetScanner scanner;
+    build(scanner, with_nullable);
+    std::vector<ExprContext*> ctxs;
+    conjuncts(ctxs, with_nullable);
+    std::vector<SimplePredicate*> roots;
+    CHECK(CreateSimplePredicates(&scanner, ctxs, &roots));
+    for (SimplePredicate* r : roots) scanner.AddSimplePredicate(r);
+    // the vectorised loop of AssembleRows (.cc:1101-1182): batches, skip list, late materialisation
+    int64_t row = 0;
+    int64_t selected = 0;
+    while (row < n) {
+      SkipBitset bs;
+      CHECK(scanner.EvalSimplePredicates(bs));
+      const int64_t batch = (int64_t)bs.size();
+      CHECK(batch == std::min<int64_t>(1024, n - row));
+      for (int64_t i = 0; i < batch; ++i) CHECK(bs[(size_t)i] == expect((int)(row + i), with_nullable));
+      std::vector<int> skip_rows;
+      int last_skip_rows = 0;
+      HdfsParquetScanner::BitsetToSkipList(bs, &skip_rows, &last_skip_rows);
+      int64_t r = row;
+      for (int skip : skip_rows) {
+        r += skip;
+        int32_t v0; int64_t v1; int32_t v2;
+        CHECK(scanner.ReadValue(0, &v0, skip) && v0 == c0[r]);
+        CHECK(scanner.ReadValue(1, &v1, skip) && v1 == c1[r]);
+        CHECK(scanner.ReadValue(2, &v2, skip) && v2 == c2[r]);
+        if (with_nullable) {
+          int32_t v3; bool is_null;
+          CHECK(scanner.ReadValue(3, &v3, skip, &is_null) && !is_null && v3 == c3[r]);
+        }
+        ++r; ++selected;
+      }
+      if (last_skip_rows) {
+        for (int c = 0; c < 3 + with_nullable; ++c) scanner.SkipValue(c, last_skip_rows);
+      }
+      row += batch;
+    }
+    CHECK(selected > 0);
+    if (!with_nullable) {  // one-launch program over all rows
+      HdfsParquetScanner s2;
+      build(s2, false);
+      std::vector<ExprContext*> ctxs2;
+      conjuncts(ctxs2, false);
+      std::vector<SimplePredicate*> roots2;
+      CHECK(CreateSimplePredicates(&s2, ctxs2, &roots2));
+      for (SimplePredicate* r : roots2) s2.AddSimplePredicate(r);
+      std::vector<uint64_t> words;
+      CHECK(s2.EvalSimplePredicatesFused(n, &words));
+      for (int i = 0; i < n; ++i) CHECK((bool)((words[(size_t)i >> 6] >> (i & 63)) & 1) == expect(i, false));
+      for (ExprContext* c : ctxs2) delete c;
+    }
+    for (ExprContext* c : ctxs) delete c;
+  }
+  // shapes the reference refuses to lower (scalar-fn-call.cc:740-746, 945-962)
+  HdfsParquetScanner s;
+  ExprContext slot_vs_slot(new ScalarFnCall("eq", new SlotRef(TYPE_INT, 0), {new SlotRef(TYPE_INT, 1)}));
+  ExprContext bool_lit(new ScalarFnCall("eq", new SlotRef(TYPE_INT, 0), {new Literal(TYPE_BOOLEAN, (int64_t)1)}));
+  ExprContext unknown_fn(new ScalarFnCall("ne", new SlotRef(TYPE_INT, 0), {new Literal(TYPE_INT, (int64_t)1)}));
+  CHECK(slot_vs_slot.CreateSimplePredicates(&s) == NULL);
+  CHECK(bool_lit.CreateSimplePredicates(&s) == NULL);
+  CHECK(unknown_fn.CreateSimplePredicates(&s) == NULL);
+}
+
+int main() {
+  int count = 0;
+  if (ips_device_count(&count) != IPS_OK || count == 0) {
+    fprintf(stderr, "facade_test: no GPU: %s\n", ips_last_error());
+    return 2;
+  }
+  TestFleSpecificSequences();
+  TestFleValues();
+  TestFlePredicates();
+  TestNumbersAll<int8_t>(); TestNumbersAll<int16_t>(); TestNumbersAll<int32_t>();
+  TestNumbersAll<int64_t>(); TestNumbersAll<float>(); TestNumbersAll<double>();
+  TestDictPredicates<int32_t>(); TestDictPredicates<int64_t>(); TestDictPredicates<double>();
+  TestDictPredicates<int16_t>(); TestDictPredicates<float>();
+  TestScanner();
+  CHECK(ips::sticky_status() == IPS_OK);
+  printf("facade_test: %d checks, %d failed\n", g_checks, g_fail);
+  return g_fail ? 1 : 0;
+}

@@ -1,0 +1,69 @@
+"""CPU test of the multi-GPU path's host logic (world_size 2, gloo): row stripes are cut on
+2048-row boundaries, each rank produces the bitmap of its stripe (the oracle stands in for the HIP
+kernel here -- no GPU in this container), the stripes' bitmap words are all-gathered, and the
+result must be bit-identical to the single-process bitmap of the whole column."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n_rows, bw, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import __graft_entry__ as g
+    from oracle import oracle as O
+    sharding = g.load_package().sharding
+    synth = g.load_package().synth
+    vals = synth.column_u32(synth.SEED_HEADLINE, n_rows, bw)
+    enc = O.fle_encode(vals, bw)
+    c = synth.lt_constant(bw)
+    row0, row1 = sharding.stripe_bounds(n_rows, world, rank)
+    mine = sharding.stripe_word_slice(enc, bw, n_rows, world, rank)
+    local = O.fle_pred(mine, row1 - row0, bw, O.OP_LT, c) if row1 > row0 else np.zeros(0, np.uint64)
+    full = sharding.allgather_bitmap(torch.from_numpy(local.view(np.int64).copy()), n_rows, world)
+    whole = O.fle_pred(enc, n_rows, bw, O.OP_LT, c)
+    ok = np.array_equal(full.numpy().view(np.uint64), whole)
+    # every rank sees the same gathered bitmap
+    t = torch.tensor([int(ok)])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        ret.put(bool(t.item()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows,bw", [(10000, 12), (2048 * 7 + 5, 32), (100, 4), (2048 * 2, 9)])
+def test_allgather_of_stripe_bitmaps(n_rows, bw):
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29500 + (os.getpid() + n_rows) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_rows, bw, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=10) is True
+
+
+def test_stripe_geometry():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    sh = g.load_package().sharding
+    for n in (1, 2047, 2048, 2049, 600_037_902):
+        for world in (1, 2, 4, 8):
+            s = sh.stripe_rows(n, world)
+            assert s % 2048 == 0 and s * world >= n
+            bounds = [sh.stripe_bounds(n, world, r) for r in range(world)]
+            assert bounds[0][0] == 0 and bounds[-1][1] == n
+            for (a0, a1), (b0, b1) in zip(bounds, bounds[1:]):
+                assert a1 == b0 and (a0 % 2048 == 0 or a0 == a1)
