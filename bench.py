@@ -187,24 +187,31 @@ def main():
     if not args.no_cpu and world == 1:
         nc = min(args.cpu_rows, n)
         enc_h = enc[: (nc // 64) * bw].cpu().numpy().view(np.uint64)
-        threads = O.hw_threads()
-        best = {}
-        for mode in (0, 1):
-            O.bench_fused(enc_h, nc, bw, O.OP_LT, c, threads, mode)  # warm-up
-            ts = []
-            for _ in range(5):
-                t = time.perf_counter()
-                cnt, _, _ = O.bench_fused(enc_h, nc, bw, O.OP_LT, c, threads, mode)
-                ts.append(time.perf_counter() - t)
-            best[mode] = nc / min(ts)
-        cpu = {"value": round(max(best.values()), 1), "unit": "rows/s", "cores": threads,
+        # thread counts to try: what the container may really use (affinity / cgroup quota) and
+        # every online CPU; the better one is reported with its own thread count
+        cands = sorted({O.hw_threads(), min(os.cpu_count() or 1, 256)})
+        best, best_threads = {}, {}
+        for threads in cands:
+            for mode in (0, 1):
+                O.bench_fused(enc_h, nc, bw, O.OP_LT, c, threads, mode)  # warm-up
+                ts = []
+                for _ in range(5):
+                    t = time.perf_counter()
+                    O.bench_fused(enc_h, nc, bw, O.OP_LT, c, threads, mode)
+                    ts.append(time.perf_counter() - t)
+                rate = nc / min(ts)
+                if rate > best.get(mode, 0.0):
+                    best[mode], best_threads[mode] = rate, threads
+        top = max(best, key=best.get)
+        cpu = {"value": round(best[top], 1), "unit": "rows/s", "cores": best_threads[top],
                "kind": "port",
                "sample": (f"first {nc} rows of the same column, same LT constant; oracle C port "
                           f"(scalar uint64 predicate as fle-encoding.h:8012-8066 + SWAR block unpack"
-                          f"{', avx2 clones' if O.has_avx2() else ''}), one stripe per thread, best of 5; "
-                          f"one call per stripe {best[0]:.3e} rows/s, reference-shaped 1024-row "
-                          f"batches {best[1]:.3e} rows/s"),
-               "single_thread_note": "the reference itself is unbuildable in this image (Boost/Impala headers absent)"}
+                          f"{', avx2 clones' if O.has_avx2() else ''}), one stripe per thread, best of 5, "
+                          f"thread counts tried {cands}; one call per stripe {best[0]:.3e} rows/s "
+                          f"({best_threads[0]} threads), reference-shaped 1024-row batches "
+                          f"{best[1]:.3e} rows/s ({best_threads[1]} threads)"),
+               "note": "the reference itself is unbuildable in this image (Boost/Impala headers absent), hence kind=port"}
 
     total_rows = n * world
     out = {

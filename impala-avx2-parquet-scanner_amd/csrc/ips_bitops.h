@@ -76,6 +76,19 @@ IPS_HD void transpose_stage(uint32_t (&a)[32]) {
   for (int k = 0; k < 32; ++k) {
     if ((k & J) == 0) {
       uint32_t lo = a[k], hi = a[k + J];
+#if defined(__HIP_DEVICE_COMPILE__)
+      // the two byte-granular stages are single v_perm_b32 byte shuffles of {hi, lo}
+      if (J == 16) {
+        a[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);       // lo.b0 lo.b1 hi.b0 hi.b1
+        a[k + J] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);   // lo.b2 lo.b3 hi.b2 hi.b3
+        continue;
+      }
+      if (J == 8) {
+        a[k] = __builtin_amdgcn_perm(hi, lo, 0x06020400u);       // lo.b0 hi.b0 lo.b2 hi.b2
+        a[k + J] = __builtin_amdgcn_perm(hi, lo, 0x07030501u);   // lo.b1 hi.b1 lo.b3 hi.b3
+        continue;
+      }
+#endif
       a[k] = (lo & M) | ((hi << J) & ~M);
       a[k + J] = ((lo >> J) & M) | (hi & ~M);
     }

@@ -208,62 +208,34 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
   return x;
 }
 
-// Two LDS images of the compacted sub-tile, chosen per sub-tile by its (wave-uniform) count:
-//  - sparse (count <= kSparseMax): element P at dword P.  Few lanes are active per step, so bank
-//    conflicts are rare and the address is a running pointer.
-//  - dense: element P at dword P + P/32.  The one-dword pad per 32 elements keeps the per-lane
-//    scatter conflict-free up to 100 % selectivity (lane l writes element 32*l + j in step j:
-//    bank (j + l) mod 32).
-#ifndef IPS_SPARSE_VARIANT
-#define IPS_SPARSE_VARIANT 0
-#endif
-constexpr uint32_t kSparseMax = 320;  // 15.6 % of 2048 rows
-__device__ __forceinline__ uint32_t compact_dw(uint32_t P, bool dense) {
-  return dense ? P + (P >> 5) : P;
-}
+// Dense compaction image: element P of the sub-tile's selected rows lives at dword P + P/32 of the
+// wave's LDS region.  The one-dword pad per 32 elements keeps the per-lane scatter below
+// conflict-free up to 100 % selectivity (lane l writes element 32*l + j in step j: bank
+// (j + l) mod 32).
+__device__ __forceinline__ uint32_t compact_dw(uint32_t P) { return P + (P >> 5); }
 
-// Each lane appends the selected ones of its own 32 rows (v[j] <-> bit j of bm) behind those of
-// all lower lanes: no cross-lane traffic besides the prefix sum.  Returns the sub-tile's count.
-// The caller fences before (the region still holds the planes) and after.
-__device__ __forceinline__ uint32_t compact_lane_values(uint32_t* lds32, uint32_t bm,
-                                                        const uint32_t (&v)[32]) {
-  const uint32_t mine = (uint32_t)__builtin_popcount(bm);
-  const uint32_t incl = wave_inclusive_scan(mine);
-  const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-  uint32_t P = incl - mine;
-  if (total <= kSparseMax) {
-#if IPS_SPARSE_VARIANT == 1
-    // position from a popcount inside the branch: steps in which no lane selects row j are
-    // skipped whole (s_cbranch_execz), which is most steps below ~2 % selectivity
+// A sub-tile takes the sparse path when no lane selected more than this many of its 32 rows
+// (always the case up to ~15 % selectivity): 3 rounds of 4 rows.
+constexpr uint32_t kSparseLaneMax = 12;
+
+// Dense path: each lane appends the selected ones of its own 32 rows (v[j] <-> bit j of bm) behind
+// those of all lower lanes (P = exclusive prefix of the per-lane counts).  32 predicated LDS
+// stores; the caller fences before (the region still holds the planes) and after.
+__device__ __forceinline__ void compact_lane_values(uint32_t* lds32, uint32_t bm, uint32_t P,
+                                                    const uint32_t (&v)[32]) {
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      if (bm & (1u << j)) lds32[P + (uint32_t)__builtin_popcount(bm & ((1u << j) - 1u))] = v[j];
-    }
-#else
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const bool sel = (bm & (1u << j)) != 0u;
-      if (sel) lds32[P] = v[j];
-      P += sel ? 1u : 0u;
-    }
-#endif
-  } else {
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const bool sel = (bm & (1u << j)) != 0u;
-      if (sel) lds32[P + (P >> 5)] = v[j];
-      P += sel ? 1u : 0u;
-    }
+  for (int j = 0; j < 32; ++j) {
+    const bool sel = (bm & (1u << j)) != 0u;
+    if (sel) lds32[P + (P >> 5)] = v[j];
+    P += sel ? 1u : 0u;
   }
-  return total;
 }
 
 // compacted LDS image [0, count) -> dst[0, count), coalesced 16-byte stores; dst 16-byte aligned.
 __device__ __forceinline__ void store_compacted(const uint32_t* lds32, uint32_t count,
                                                 uint32_t* __restrict__ dst, int lane) {
-  const bool dense = count > kSparseMax;
   for (uint32_t p = 4u * lane; p < count; p += 4u * kWave) {
-    const uint32_t* src = lds32 + compact_dw(p, dense);  // 4 elements never straddle a pad
+    const uint32_t* src = lds32 + compact_dw(p);  // 4 elements never straddle a pad
     if (p + 4 <= count) {
       u32x4 t = {src[0], src[1], src[2], src[3]};
       *reinterpret_cast<u32x4*>(dst + p) = t;

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kerne
     const typename GatherT<G>::type* __restrict__ dict, uint32_t dict_entries,
     int32_t* __restrict__ bad_index) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kRowTileBytes / 4];
+  using GT = typename GatherT<G>::type;
   constexpr int L = (16 * W + kWave - 1) / kWave;
   const int lane = lane_id();
   const int wave = wave_id();
@@ -71,20 +72,60 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kerne
     if (__builtin_amdgcn_ballot_w64(bm != 0u) != 0ull) {  // wave-uniform: any row selected
       uint32_t v[32];
       planes_to_values<W>(p, v);
+      const uint32_t mine = (uint32_t)__builtin_popcount(bm);
+      const uint32_t incl = wave_inclusive_scan(mine);
+      count = __builtin_amdgcn_readlane(incl, 63);
+      uint32_t P = incl - mine;  // this lane's first output slot inside the batch
+      GT* dst = batch_values + tile * kRowsPerTile;
       wave_lds_fence();  // all plane reads precede the overwrite of the same LDS region
-      count = compact_lane_values(lds32, bm, v);
-      wave_lds_fence();
-      if (G == 0) {
-        store_compacted(lds32, count, reinterpret_cast<uint32_t*>(batch_values) +
-                                          tile * kRowsPerTile, lane);
-      } else {
-        typename GatherT<G>::type* dst = batch_values + tile * kRowsPerTile;
+      if (__builtin_amdgcn_ballot_w64(mine > kSparseLaneMax) == 0ull) {
+        // Sparse path (the common case up to ~15 % selectivity).  Each lane parks its 32 values
+        // in its own slot of the row tile (8 x 16-byte LDS stores, no cross-lane traffic) and
+        // walks the set bits of its mask, four per round, scattering straight to the batch in
+        // HBM: the stores of a round cover consecutive slots of consecutive lanes.
+        values_to_row_tile(lds32, lane, v);
+        const uint32_t* mine_lds = lds32 + lane * kRowTileStrideDw;
+        uint32_t m = bm;
         int bad = 0;
-        for (uint32_t e = lane; e < count; e += kWave) {
-          uint32_t code = lds32[compact_dw(e, count > kSparseMax)];
-          if (code < dict_entries) dst[e] = dict[code]; else bad = 1;
+#pragma unroll 1
+        for (int round = 0; round < (int)kSparseLaneMax / 4; ++round) {
+          if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) break;
+          uint32_t x[4];
+          bool ok[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            ok[e] = m != 0u;
+            x[e] = mine_lds[ok[e] ? __builtin_ctz(m) : 0];
+            m &= m - 1u;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (ok[e]) {
+              if (G == 0) {
+                dst[P] = (GT)x[e];
+              } else if (x[e] < dict_entries) {
+                dst[P] = dict[x[e]];
+              } else {
+                bad = 1;
+              }
+              ++P;
+            }
+          }
         }
-        if (bad && bad_index) *bad_index = 1;
+        if (G != 0 && bad && bad_index) *bad_index = 1;
+      } else {
+        compact_lane_values(lds32, bm, P, v);
+        wave_lds_fence();
+        if (G == 0) {
+          store_compacted(lds32, count, reinterpret_cast<uint32_t*>(dst), lane);
+        } else {
+          int bad = 0;
+          for (uint32_t e = lane; e < count; e += kWave) {
+            uint32_t code = lds32[compact_dw(e)];
+            if (code < dict_entries) dst[e] = dict[code]; else bad = 1;
+          }
+          if (bad && bad_index) *bad_index = 1;
+        }
       }
     }
     if (lane == 0) batch_counts[tile] = count;

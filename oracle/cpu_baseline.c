@@ -11,16 +11,49 @@
  * shuffle/cmpeq sequences, fle-encoding.h:569-7329); gcc vectorises the widening loops under
  * the avx2 target clone when the host supports it.
  */
+#define _GNU_SOURCE
 #include <pthread.h>
+#include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 
 #include "fle_oracle.h"
 
+/* Host threads this process can really use: min(online CPUs, affinity mask, cgroup CPU quota).
+ * A GPU box advertises all host CPUs but the container gets a share of them. */
 int orc_hw_threads(void) {
   long n = sysconf(_SC_NPROCESSORS_ONLN);
-  return n > 0 ? (int)n : 1;
+  if (n < 1) n = 1;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+    int c = CPU_COUNT(&set);
+    if (c > 0 && c < n) n = c;
+  }
+  FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r"); /* cgroup v2: "<quota> <period>" or "max ..." */
+  if (f) {
+    char q[64];
+    long period = 0;
+    if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      long quota = atol(q);
+      long c = (quota + period - 1) / period;
+      if (c > 0 && c < n) n = c;
+    }
+    fclose(f);
+  } else {
+    long quota = -1, period = 0; /* cgroup v1 */
+    FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+    FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+    if (fq && fp && fscanf(fq, "%ld", &quota) == 1 && fscanf(fp, "%ld", &period) == 1 &&
+        quota > 0 && period > 0) {
+      long c = (quota + period - 1) / period;
+      if (c > 0 && c < n) n = c;
+    }
+    if (fq) fclose(fq);
+    if (fp) fclose(fp);
+  }
+  return (int)n;
 }
 
 int orc_has_avx2(void) {
