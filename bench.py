@@ -53,7 +53,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # the exchange step runs whenever there is more than one rank (IPS_BENCH_GATHER=1 forces it
+    # under a 1-rank torchrun launch, to rehearse the code path on a single-GPU box)
+    gather = world > 1 or (os.environ.get("IPS_BENCH_GATHER") == "1" and "RANK" in os.environ)
+    if gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # nccl IS RCCL on ROCm
@@ -84,18 +87,36 @@ def main():
 
     outputs = capi.alloc_scan_outputs(n, dev)
     words = (n + 63) // 64
-    full_bitmap = torch.empty(words * world, dtype=torch.int64, device=dev) if world > 1 else None
     stream = torch.cuda.current_stream()
+    # Exchange: the scan of step i+1 overlaps the all-gather of step i's bitmap (RCCL runs on its
+    # own stream), so the local bitmap and the gathered bitmap are double-buffered.
+    local_bm = [outputs[0], torch.empty_like(outputs[0])] if gather else [outputs[0]]
+    full_bm = [torch.empty(words * world, dtype=torch.int64, device=dev) for _ in range(2)] \
+        if gather else None
+    pending = [None]
 
-    def step():
-        bitmap, bvals, counts = capi.fle_scan(enc, n, bw, capi.OP_LT, c, outputs=outputs)
-        if world > 1:
-            dist.all_gather_into_tensor(full_bitmap, bitmap)
+    def step(i):
+        k = i & 1 if gather else 0
+        outs = (local_bm[k], outputs[1], outputs[2])
+        bitmap, bvals, counts = capi.fle_scan(enc, n, bw, capi.OP_LT, c, outputs=outs)
+        if gather:
+            work = dist.all_gather_into_tensor(full_bm[k], local_bm[k][:words], async_op=True)
+            if pending[0] is not None:
+                pending[0].wait()  # stream-side wait: buffer k^1 is free before step i+1 reuses it
+            pending[0] = work
         return bitmap, bvals, counts
 
-    for _ in range(args.warmup):
-        bitmap, bvals, counts = step()
-    torch.cuda.synchronize()
+    def drain():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        bitmap, bvals, counts = step(i)
+    if args.warmup == 0:
+        bitmap, bvals, counts = step(0)
+    drain()
     n_sel = int(counts.to(torch.int64).sum().item())
     if rank == 0:
         n1 = min(n, 1 << 20)
@@ -116,30 +137,41 @@ def main():
     # ---- timed region: exactly K steps, barrier + synchronize on both sides ------------------
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
-    if world > 1:
+    if gather:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        k = i & 1 if gather else 0
         ev[i][0].record(stream)
-        capi.fle_scan(enc, n, bw, capi.OP_LT, c, outputs=outputs)
+        capi.fle_scan(enc, n, bw, capi.OP_LT, c, outputs=(local_bm[k], outputs[1], outputs[2]))
         ev[i][1].record(stream)
-        if world > 1:
-            dist.all_gather_into_tensor(full_bitmap, outputs[0][:words])
-    torch.cuda.synchronize()
-    if world > 1:
+        if gather:
+            work = dist.all_gather_into_tensor(full_bm[k], local_bm[k][:words], async_op=True)
+            if pending[0] is not None:
+                pending[0].wait()
+            pending[0] = work
+    drain()
+    if gather:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if gather:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
-    if world > 1:  # bit-identity of the gathered bitmap: slice r equals rank r's local bitmap
-        mine = full_bitmap[rank * words:(rank + 1) * words]
-        assert torch.equal(mine, outputs[0][:words])
+    if gather:  # bit-identity: slice r of every gathered bitmap equals rank r's local bitmap
+        for k in range(min(2, args.steps)):
+            mine = full_bm[k][rank * words:(rank + 1) * words]
+            assert torch.equal(mine, local_bm[k][:words]), "gathered bitmap differs from local"
+        if world > 1:  # and every rank holds the same gathered words
+            chk = full_bm[0].sum().reshape(1).clone()
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert int(lo.item()) == int(hi.item()), "ranks disagree on the gathered bitmap"
 
     # ---- 1M-row single-chunk latency (config 1/2 literally: launch-bound) ---------------------
     n1 = 1 << 20
@@ -159,7 +191,7 @@ def main():
         lat_us = e0.elapsed_time(e1) * 1000.0 / reps
 
     if rank != 0:
-        if world > 1:
+        if gather:
             dist.destroy_process_group()
         return
 
@@ -226,8 +258,9 @@ def main():
                          "(the 2^20-row single-chunk launch is latency-bound, see extra.latency)"),
             "rows_per_gpu": n, "bit_width": bw, "predicate": f"LT {c}",
             "selectivity": round(n_sel / n, 5), "batch_rows": capi.BATCH_ROWS,
-            "parallelism": (f"{world} row stripes, RCCL all-gather of bitmap words per step"
-                            if world > 1 else "single GPU"),
+            "parallelism": (f"{world} row stripes, RCCL all-gather of bitmap words per step "
+                            "(gather of step i overlaps the scan of step i+1)"
+                            if gather else "single GPU"),
         },
         "roofline": roofline, "cpu_baseline": cpu,
         "extra": {"check": check, "selected_rows": n_sel,
@@ -235,7 +268,7 @@ def main():
                   "device": capi.device_info()[0]},
     }
     print(json.dumps(out))
-    if world > 1:
+    if gather:
         dist.destroy_process_group()
 
 
