@@ -88,9 +88,11 @@ __device__ __forceinline__ void tile_load(const uint64_t* __restrict__ enc, int6
 }
 
 // ---- VGPR -> LDS (odd word stride per block) ------------------------------------------------
+// inv_w = floor(2^32 / w) + 1 when the caller has it (w changes at run time inside the kernel):
+// word / w == umulhi(word, inv_w) exactly for word < 2^16; 0 = divide.
 template <int MAXLOADS>
 __device__ __forceinline__ void tile_to_lds(uint32_t* lds32, int w, int lane,
-                                            const u32x4 (&r)[MAXLOADS]) {
+                                            const u32x4 (&r)[MAXLOADS], uint32_t inv_w = 0u) {
   const int chunks = 16 * w;
   const int stride = w | 1;
   if (w & 1) {  // stride == w: the LDS image is linear, one 16-byte store per chunk
@@ -105,7 +107,7 @@ __device__ __forceinline__ void tile_to_lds(uint32_t* lds32, int w, int lane,
       int c = i * kWave + lane;
       if (c < chunks) {
         int wi = 2 * c;
-        int blk = wi / w;
+        int blk = inv_w ? (int)__umulhi((uint32_t)wi, inv_w) : wi / w;
         int k = wi - blk * w;
         uint32_t* dst = lds32 + 2 * (blk * stride + k);
         u32x2 lo = {r[i].x, r[i].y}, hi = {r[i].z, r[i].w};
@@ -128,22 +130,30 @@ __device__ __forceinline__ uint32_t pred_single_from_lds(const uint32_t* lds32, 
   const uint32_t* p = lds32 + plane_base_dw(w, lane);
   CmpState s{0u, ~0u};
   int k = w - 1;
-  for (; k >= 3; k -= 4) {  // 4 independent LDS reads in flight per step
+  for (; k >= 7; k -= 8) {  // 8 independent LDS reads in flight per round trip
+    uint32_t x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = p[2 * (k - e)];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cmp_step(s, x[e], bit_mask(c, k - e));
+  }
+  if (k >= 3) {  // then 4
     uint32_t x3 = p[2 * k], x2 = p[2 * k - 2], x1 = p[2 * k - 4], x0 = p[2 * k - 6];
     cmp_step(s, x3, bit_mask(c, k));
     cmp_step(s, x2, bit_mask(c, k - 1));
     cmp_step(s, x1, bit_mask(c, k - 2));
     cmp_step(s, x0, bit_mask(c, k - 3));
+    k -= 4;
   }
-  for (; k >= 0; --k) cmp_step(s, p[2 * k], bit_mask(c, k));
+  for (; k >= 0; --k) cmp_step(s, p[2 * k], bit_mask(c, k));  // 0..3 planes left
   return cmp_select(s, op);
 }
 
 // IN: the planes are re-read from LDS once per constant, never from HBM (the reference makes K
 // full passes over the block's words as well, fle-encoding.h:8283-8290).
-template <typename CT>
+template <typename ConstsPtrT>
 __device__ __forceinline__ uint32_t pred_in_from_lds(const uint32_t* lds32, int w, int lane,
-                                                     const CT* consts, int n_consts) {
+                                                     ConstsPtrT consts, int n_consts) {
   const uint32_t* p = lds32 + plane_base_dw(w, lane);
   uint32_t any = 0u;
 #pragma unroll 1

@@ -13,32 +13,121 @@ namespace ips {
 
 constexpr int kMaxLeaves = 16;
 constexpr int kStackDepth = 8;
+constexpr int kMaxJobs = 2 * kMaxLeaves;  // an 8-byte PLAIN leaf stages its sub-tile in two halves
 
-struct ProgLeaf {
+// One 16-byte descriptor per program node: a single broadcast ds_read_b128 per node at run time.
+struct NodeDesc {
+  int8_t kind;       // ips_node_kind
+  int8_t encoding;   // leaf: ips_col_encoding
+  int8_t type;       // leaf: ips_type (PLAIN)
+  int8_t n_stage;    // leaf: staging jobs to run before evaluating (0 = the previous leaf staged
+                     //       the same column, e.g. BETWEEN = And(Ge, Le); 2 = 8-byte PLAIN halves)
+  int8_t op;
+  int8_t n_consts;
+  int8_t bit_width;
+  int8_t leaf_fuse;  // bits 0..3: index into consts[][]; bits 4..5: the AND/OR node that follows
+                     // this leaf and has been folded into it (0 none, 1 AND, 2 OR)
+  uint32_t const_lo, const_hi;  // consts[leaf][0]
+};
+
+// One staging job = one <= 8 KiB piece of one column's sub-tile: 8 x 16 bytes per lane.
+enum JobKind { kJobFle = 0, kJobPlain4 = 1, kJobPlain8Lo = 2, kJobPlain8Hi = 3 };
+struct JobDesc {
   const void* data;
-  int32_t encoding;  // ips_col_encoding
-  int32_t bit_width;
-  int32_t type;      // ips_type (PLAIN)
-  int32_t op;
-  int32_t n_consts;
-  int32_t pad;
-  uint64_t consts[16];
+  int32_t kind_width;  // kind | bit_width << 8
+  uint32_t inv_width;  // floor(2^32 / bit_width) + 1 (FLE): block index without a division
 };
 
 struct Program {
   int32_t n_nodes;
-  int32_t n_leaves;
-  int8_t kind[IPS_PROGRAM_MAX_NODES];   // ips_node_kind
-  int8_t leaf[IPS_PROGRAM_MAX_NODES];   // index into leaves for kind == LEAF
-  ProgLeaf leaves[kMaxLeaves];
+  int32_t n_jobs;
+  int32_t pad[2];
+  NodeDesc nodes[IPS_PROGRAM_MAX_NODES];
+  JobDesc jobs[kMaxJobs];
+  uint64_t consts[kMaxLeaves][16];
+};
+static_assert(sizeof(NodeDesc) == 16 && sizeof(JobDesc) == 16, "descriptor layout");
+static_assert(sizeof(Program) % 16 == 0 && sizeof(Program) <= 3968, "kernarg budget");
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---- staging: HBM -> VGPR (issued one job ahead) and VGPR -> LDS ------------------------------
+__device__ __forceinline__ void job_load(const void* data, int kind, int w, int64_t tile,
+                                         int64_t n_rows, int lane, u32x4 (&r)[8]) {
+  if (kind == kJobFle) {
+    tile_load<8>(reinterpret_cast<const uint64_t*>(data), tile, w, ((n_rows + 63) / 64) * w, lane, r);
+  } else if (kind == kJobPlain4) {
+    const uint32_t* page = reinterpret_cast<const uint32_t*>(data);
+    const int64_t row_base = tile * kRowsPerTile;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rho = 4 * (i * kWave + lane);
+      const int64_t valid = n_rows - (row_base + rho);
+      u32x4 t = {0u, 0u, 0u, 0u};
+      if (valid >= 4) {
+        t = *reinterpret_cast<const u32x4*>(page + row_base + rho);
+      } else {
+        if (valid > 0) t.x = page[row_base + rho];
+        if (valid > 1) t.y = page[row_base + rho + 1];
+        if (valid > 2) t.z = page[row_base + rho + 2];
+      }
+      r[i] = t;
+    }
+  } else {
+    const uint64_t* page = reinterpret_cast<const uint64_t*>(data);
+    const int64_t row_base = tile * kRowsPerTile + (kind == kJobPlain8Hi ? 1024 : 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rr = 2 * (i * kWave + lane);
+      const int64_t valid = n_rows - (row_base + rr);
+      u32x4 t = {0u, 0u, 0u, 0u};
+      if (valid >= 2) {
+        t = *reinterpret_cast<const u32x4*>(page + row_base + rr);
+      } else if (valid > 0) {
+        u32x2 q = *reinterpret_cast<const u32x2*>(page + row_base + rr);
+        t.x = q.x; t.y = q.y;
+      }
+      r[i] = t;
+    }
+  }
+}
+
+__device__ __forceinline__ void job_to_lds(int kind, int w, uint32_t inv_w, uint32_t* lds32,
+                                           int lane, const u32x4 (&r)[8]) {
+  if (kind == kJobFle) {
+    tile_to_lds<8>(lds32, w, lane, r, inv_w);
+  } else if (kind == kJobPlain4) {  // padded row tile: lane l later reads its 32 rows
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      *reinterpret_cast<u32x4*>(lds32 + row_tile_dw(4 * (i * kWave + lane))) = r[i];
+  } else {  // 1024 8-byte rows: row rr at dword (rr>>4)*36 + (rr&15)*2
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rr = 2 * (i * kWave + lane);
+      *reinterpret_cast<u32x4*>(lds32 + (rr >> 4) * kRowTileStrideDw + (rr & 15) * 2) = r[i];
+    }
+  }
+}
+
+// ---- PLAIN leaves: compare this lane's 32 consecutive rows -----------------------------------
+template <typename T>
+__device__ __forceinline__ T as_literal(uint64_t raw) {
+  T lit;
+  __builtin_memcpy(&lit, &raw, sizeof(T));
+  return lit;
+}
+
+struct LeafHdr {  // wave-uniform
+  int op;
+  int n_consts;
+  uint64_t const0;
+  const uint64_t* consts;  // LDS copy of the leaf's constants (IN lists)
 };
 
-// ---- PLAIN leaf: compare this lane's 32 consecutive rows (values staged in the padded row tile)
 template <typename T>
-__device__ __forceinline__ bool leaf_cmp(T x, int op, const ProgLeaf& lf) {
-  T lit;
-  __builtin_memcpy(&lit, &lf.consts[0], sizeof(T));
-  switch (op) {
+__device__ __forceinline__ bool leaf_cmp(T x, const LeafHdr& lf) {
+  const T lit = as_literal<T>(lf.const0);
+  switch (lf.op) {
     case 0: return x == lit;
     case 1: return x < lit;
     case 2: return x <= lit;
@@ -46,37 +135,14 @@ __device__ __forceinline__ bool leaf_cmp(T x, int op, const ProgLeaf& lf) {
     case 4: return x >= lit;
     default: {
       bool f = false;
-      for (int j = 0; j < lf.n_consts; ++j) {
-        T l2;
-        __builtin_memcpy(&l2, &lf.consts[j], sizeof(T));
-        f = f || (x == l2);
-      }
+      for (int j = 0; j < lf.n_consts; ++j) f = f || (x == as_literal<T>(lf.consts[j]));
       return f;
     }
   }
 }
 
-// 4-byte slots: the wave stages 2048 slots (8 KiB) in the row-tile layout, lane reads its 32.
 template <typename T>
-__device__ __forceinline__ uint32_t plain_leaf_4(const ProgLeaf& lf, uint32_t* lds32, int64_t tile,
-                                                 int64_t n_rows, int lane) {
-  const int64_t row_base = tile * kRowsPerTile;
-  const uint32_t* page = reinterpret_cast<const uint32_t*>(lf.data);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    int rho = 4 * (i * kWave + lane);
-    int64_t valid = n_rows - (row_base + rho);
-    u32x4 t = {0u, 0u, 0u, 0u};
-    if (valid >= 4) {
-      t = *reinterpret_cast<const u32x4*>(page + row_base + rho);
-    } else {
-      if (valid > 0) t.x = page[row_base + rho];
-      if (valid > 1) t.y = page[row_base + rho + 1];
-      if (valid > 2) t.z = page[row_base + rho + 2];
-    }
-    *reinterpret_cast<u32x4*>(lds32 + row_tile_dw(rho)) = t;
-  }
-  wave_lds_fence();
+__device__ __noinline__ uint32_t plain4_eval(const LeafHdr lf, const uint32_t* lds32, int lane) {
   uint32_t bm = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -87,55 +153,33 @@ __device__ __forceinline__ uint32_t plain_leaf_4(const ProgLeaf& lf, uint32_t* l
       T x;
       if constexpr (sizeof(T) == 4) __builtin_memcpy(&x, &raw[e], 4);
       else x = (T)(int32_t)raw[e];
-      if (leaf_cmp<T>(x, lf.op, lf)) bm |= 1u << (4 * i + e);
+      if (leaf_cmp<T>(x, lf)) bm |= 1u << (4 * i + e);
     }
   }
-  wave_lds_fence();
   return bm;
 }
 
-// 8-byte slots: two half-tiles of 1024 rows; in half h lanes 32h..32h+31 own the staged rows.
+// half h of the sub-tile is staged: lanes 32h..32h+31 own its rows (two 16-row groups each)
 template <typename T>
-__device__ __forceinline__ uint32_t plain_leaf_8(const ProgLeaf& lf, uint32_t* lds32, int64_t tile,
-                                                 int64_t n_rows, int lane) {
-  const uint64_t* page = reinterpret_cast<const uint64_t*>(lf.data);
+__device__ __noinline__ uint32_t plain8_eval(const LeafHdr lf, const uint32_t* lds32, int lane,
+                                             int h) {
   uint32_t bm = 0;
-#pragma unroll 1
-  for (int h = 0; h < 2; ++h) {
-    const int64_t row_base = tile * kRowsPerTile + h * 1024;
-    // stage: 1024 slots = 512 chunks of 16 bytes; row r at dword (r>>4)*36 + (r&15)*2
+  if ((lane >> 5) == h) {
+    const int g0 = 2 * (lane & 31);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int r = 2 * (i * kWave + lane);
-      int64_t valid = n_rows - (row_base + r);
-      u32x4 t = {0u, 0u, 0u, 0u};
-      if (valid >= 2) {
-        t = *reinterpret_cast<const u32x4*>(page + row_base + r);
-      } else if (valid > 0) {
-        u32x2 q = *reinterpret_cast<const u32x2*>(page + row_base + r);
-        t.x = q.x; t.y = q.y;
-      }
-      *reinterpret_cast<u32x4*>(lds32 + (r >> 4) * kRowTileStrideDw + (r & 15) * 2) = t;
-    }
-    wave_lds_fence();
-    if ((lane >> 5) == h) {
-      const int g0 = 2 * (lane & 31);  // this lane's two 16-row groups
+    for (int g = 0; g < 2; ++g) {
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
+      for (int i = 0; i < 8; ++i) {
+        u32x4 t = *reinterpret_cast<const u32x4*>(lds32 + (g0 + g) * kRowTileStrideDw + 4 * i);
+        uint64_t raw[2] = {((uint64_t)t.y << 32) | t.x, ((uint64_t)t.w << 32) | t.z};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          u32x4 t = *reinterpret_cast<const u32x4*>(lds32 + (g0 + g) * kRowTileStrideDw + 4 * i);
-          uint64_t raw[2] = {((uint64_t)t.y << 32) | t.x, ((uint64_t)t.w << 32) | t.z};
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            T x;
-            __builtin_memcpy(&x, &raw[e], 8);
-            if (leaf_cmp<T>(x, lf.op, lf)) bm |= 1u << (16 * g + 2 * i + e);
-          }
+        for (int e = 0; e < 2; ++e) {
+          T x;
+          __builtin_memcpy(&x, &raw[e], 8);
+          if (leaf_cmp<T>(x, lf)) bm |= 1u << (16 * g + 2 * i + e);
         }
       }
     }
-    wave_lds_fence();
   }
   return bm;
 }
@@ -146,63 +190,155 @@ __device__ __forceinline__ uint32_t mask_rows(uint32_t bm, int64_t tile, int lan
   return bm;
 }
 
+// Reading a by-value kernel argument with run-time indices makes the compiler copy all of it to
+// scratch, and scalar loads from the kernarg segment cost a dependent ~1 us chain per leaf; so the
+// workgroup copies the program once into LDS (through the constant-address-space kernarg pointer)
+// and every node is one broadcast ds_read_b128 + v_readfirstlane.
+#define IPS_KARG __attribute__((address_space(4)))
+
 __global__ __launch_bounds__(kThreads) void program_kernel(Program prog, int64_t n_rows,
                                                            uint32_t* __restrict__ bitmap32) {
-  // per wave: one tile region (row tile, also large enough for any plane tile) + the node stack
+  // per wave: one staging region (row tile, also large enough for any plane tile) + node stack
   __shared__ __attribute__((aligned(16)))
-      uint32_t lds_all[kWavesPerBlock * (kRowTileBytes / 4 + kStackDepth * kWave)];
+      uint32_t lds_all[kWavesPerBlock * (kRowTileBytes / 4 + kStackDepth * kWave) +
+                       sizeof(Program) / 4];
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)prog;
   const int lane = lane_id();
   const int wave = wave_id();
   uint32_t* lds32 = lds_all + wave * (kRowTileBytes / 4 + kStackDepth * kWave);
   uint32_t* stack = lds32 + kRowTileBytes / 4;
+  uint32_t* prog32 = lds_all + kWavesPerBlock * (kRowTileBytes / 4 + kStackDepth * kWave);
+  {
+    const IPS_KARG uint32_t* karg = (const IPS_KARG uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
+    for (int i = threadIdx.x; i < (int)(sizeof(Program) / 4); i += kThreads) prog32[i] = karg[i];
+    __syncthreads();
+  }
+  const Program* P = reinterpret_cast<const Program*>(prog32);
 
   const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
   const int64_t bm_dwords = bitmap_dwords(n_rows);
+  const int n_jobs = (int)uni((uint32_t)P->n_jobs);
+  const int n_nodes = (int)uni((uint32_t)P->n_nodes);
 
-  for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < tiles; tile += stride) {
-    int sp = 0;
+  // wave-uniform fetch of job j's descriptor
+  auto job_desc = [&](int j, const void*& data, int& kind, int& w, uint32_t& inv_w) {
+    u32x4 d = *reinterpret_cast<const u32x4*>(&P->jobs[j]);
+    data = reinterpret_cast<const void*>(((uint64_t)uni(d.y) << 32) | uni(d.x));
+    const uint32_t kw = uni(d.z);
+    kind = (int)(kw & 0xFF);
+    w = (int)(kw >> 8);
+    inv_w = uni(d.w);
+  };
+
+  int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  u32x4 r[8];  // the NEXT staging job's bytes, always one job ahead of the evaluation
+  const void* jdata; int jkind, jw; uint32_t jinv;  // descriptor of the job whose bytes are in r
+  job_desc(0, jdata, jkind, jw, jinv);
+  if (tile < tiles) job_load(jdata, jkind, jw, tile, n_rows, lane, r);
+
+  // Stack machine with the top of stack in a register.  A leaf that is immediately followed by
+  // AND/OR (every leaf of a conjunct chain, the second leaf of every BETWEEN) is folded with that
+  // node on the host: top = top OP leaf, no stack traffic.  Only real pushes / pops go through the
+  // eight spill registers, selected by the wave-uniform depth.
+  uint32_t st[kStackDepth];
+#pragma unroll
+  for (int i = 0; i < kStackDepth; ++i) st[i] = 0u;
+  (void)stack;
+  constexpr int kNodeSkip = 3;  // an AND/OR node folded into the preceding leaf
+
+  for (; tile < tiles; tile += stride) {
+    int depth = 0;  // elements on the stack, the top one lives in 'top'
+    uint32_t top = 0u;
+    int job = 0;
+    const uint32_t row_mask = mask_rows(~0u, tile, lane, n_rows);  // rows >= n_rows of this lane
 #pragma unroll 1
-    for (int n = 0; n < prog.n_nodes; ++n) {
-      const int kind = prog.kind[n];
+    for (int n = 0; n < n_nodes; ++n) {
+      const u32x4 nd = *reinterpret_cast<const u32x4*>(&P->nodes[n]);
+      const uint32_t w0 = uni(nd.x), w1 = uni(nd.y);
+      const int kind = (int)(w0 & 0xFF);
+      if (kind == kNodeSkip) continue;
       if (kind == IPS_NODE_LEAF) {
-        const ProgLeaf& lf = prog.leaves[prog.leaf[n]];
-        uint32_t bm;
-        if (lf.encoding == IPS_COL_FLE) {
-          const int w = lf.bit_width;
-          const int64_t total_words = ((n_rows + 63) / 64) * w;
-          u32x4 r[8];
-          tile_load<8>(reinterpret_cast<const uint64_t*>(lf.data), tile, w, total_words, lane, r);
-          tile_to_lds<8>(lds32, w, lane, r);
-          wave_lds_fence();
-          uint32_t sel;
-          if (lf.op != 5) sel = pred_single_from_lds(lds32, w, lane, lf.op, (uint32_t)lf.consts[0]);
-          else sel = pred_in_from_lds(lds32, w, lane, lf.consts, lf.n_consts);
-          bm = finish_bitmap_dword(sel, tile, lane, n_rows);
-          wave_lds_fence();
-        } else {
-          switch (lf.type) {
-            case IPS_T_INT8: bm = plain_leaf_4<int8_t>(lf, lds32, tile, n_rows, lane); break;
-            case IPS_T_INT16: bm = plain_leaf_4<int16_t>(lf, lds32, tile, n_rows, lane); break;
-            case IPS_T_INT32: bm = plain_leaf_4<int32_t>(lf, lds32, tile, n_rows, lane); break;
-            case IPS_T_FLOAT: bm = plain_leaf_4<float>(lf, lds32, tile, n_rows, lane); break;
-            case IPS_T_INT64: bm = plain_leaf_8<int64_t>(lf, lds32, tile, n_rows, lane); break;
-            default: bm = plain_leaf_8<double>(lf, lds32, tile, n_rows, lane); break;
+        const int encoding = (int)((w0 >> 8) & 0xFF);
+        const int type = (int)((w0 >> 16) & 0xFF);
+        const int n_stage = (int)((w0 >> 24) & 0xFF);
+        const int bit_width = (int)((w1 >> 16) & 0xFF);
+        const int leaf = (int)((w1 >> 24) & 0xF);
+        const int fuse = (int)((w1 >> 28) & 0x3);
+        const LeafHdr lf{(int)(w1 & 0xFF), (int)((w1 >> 8) & 0xFF),
+                         ((uint64_t)uni(nd.w) << 32) | uni(nd.z), &P->consts[leaf][0]};
+        uint32_t bm = 0u;
+#pragma unroll 1
+        for (int h = 0; h < (n_stage ? n_stage : 1); ++h) {
+          if (n_stage) {
+            // bring the prefetched job from VGPRs into LDS and put the following one (possibly
+            // of this wave's next sub-tile) in flight
+            wave_lds_fence();  // earlier readers of the region are done
+            job_to_lds(jkind, jw, jinv, lds32, lane, r);
+            ++job;
+            const bool wrap = job == n_jobs;  // next job belongs to this wave's next sub-tile
+            const int64_t next_tile = wrap ? tile + stride : tile;
+            job_desc(wrap ? 0 : job, jdata, jkind, jw, jinv);
+            if (next_tile < tiles) job_load(jdata, jkind, jw, next_tile, n_rows, lane, r);
+            wave_lds_fence();
           }
-          bm = mask_rows(bm, tile, lane, n_rows);
+          if (encoding == IPS_COL_FLE) {
+            uint32_t sel;
+            if (lf.op != 5) {
+              sel = pred_single_from_lds(lds32, bit_width, lane, lf.op, (uint32_t)lf.const0);
+            } else {
+              sel = 0u;
+              const uint32_t* pl = lds32 + plane_base_dw(bit_width, lane);
+#pragma unroll 1
+              for (int j = 0; j < lf.n_consts; ++j) {
+                const uint64_t cj = lf.consts[j];
+                const uint32_t c = uni((uint32_t)cj);
+                uint32_t eq = ~0u;
+                for (int k = bit_width - 1; k >= 0; --k) eq &= ~(pl[2 * k] ^ bit_mask(c, k));
+                sel |= eq;
+              }
+            }
+            bm = bitrev32(sel);
+          } else if (type == IPS_T_INT64 || type == IPS_T_DOUBLE) {
+            bm |= type == IPS_T_INT64 ? plain8_eval<int64_t>(lf, lds32, lane, h)
+                                      : plain8_eval<double>(lf, lds32, lane, h);
+          } else {
+            switch (type) {
+              case IPS_T_INT8: bm = plain4_eval<int8_t>(lf, lds32, lane); break;
+              case IPS_T_INT16: bm = plain4_eval<int16_t>(lf, lds32, lane); break;
+              case IPS_T_INT32: bm = plain4_eval<int32_t>(lf, lds32, lane); break;
+              default: bm = plain4_eval<float>(lf, lds32, lane); break;
+            }
+          }
         }
-        stack[sp * kWave + lane] = bm;
-        ++sp;
-      } else {
-        uint32_t b = stack[(sp - 1) * kWave + lane];
-        uint32_t a = stack[(sp - 2) * kWave + lane];
-        stack[(sp - 2) * kWave + lane] = kind == IPS_NODE_AND ? (a & b) : (a | b);
-        --sp;
+        bm &= row_mask;
+        if (fuse == 1) {
+          top &= bm;
+        } else if (fuse == 2) {
+          top |= bm;
+        } else {  // push
+          if (depth > 0) {
+#pragma unroll
+            for (int i = 0; i < kStackDepth; ++i)
+              if (depth - 1 == i) st[i] = top;
+          }
+          top = bm;
+          ++depth;
+        }
+      } else {  // AND / OR of the two topmost elements
+        uint32_t below = 0u;
+#pragma unroll
+        for (int i = 0; i < kStackDepth; ++i)
+          if (depth - 2 == i) below = st[i];
+        top = kind == IPS_NODE_AND ? (below & top) : (below | top);
+        --depth;
       }
     }
     const int64_t d = tile * 64 + lane;
-    if (d < bm_dwords) bitmap32[d] = stack[lane];
+    if (d < bm_dwords) bitmap32[d] = top;
   }
+#endif
 }
 
 ips_status launch_program(const Program& prog, int64_t n_rows, uint32_t* bitmap32, hipStream_t s) {
@@ -230,12 +366,14 @@ extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const
   Program prog;
   memset(&prog, 0, sizeof(prog));
   prog.n_nodes = n_nodes;
-  int depth = 0, max_depth = 0;
+  int depth = 0, max_depth = 0, n_leaves = 0;
+  const void* last_staged = nullptr;
   for (int i = 0; i < n_nodes; ++i) {
     const ips_node& nd = nodes[i];
-    prog.kind[i] = (int8_t)nd.kind;
+    NodeDesc& desc = prog.nodes[i];
+    desc.kind = (int8_t)nd.kind;
     if (nd.kind == IPS_NODE_LEAF) {
-      IPS_REQUIRE(prog.n_leaves < kMaxLeaves, "ips_eval_program: more than %d leaves", kMaxLeaves);
+      IPS_REQUIRE(n_leaves < kMaxLeaves, "ips_eval_program: more than %d leaves", kMaxLeaves);
       IPS_REQUIRE(nd.column >= 0 && nd.column < n_cols, "ips_eval_program: node %d: bad column", i);
       IPS_REQUIRE(nd.op >= IPS_OP_EQ && nd.op <= IPS_OP_IN, "ips_eval_program: node %d: bad op", i);
       IPS_REQUIRE(nd.n_consts >= 1 && nd.n_consts <= 16 && (nd.op == IPS_OP_IN || nd.n_consts == 1),
@@ -243,13 +381,6 @@ extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const
       const ips_column& c = cols[nd.column];
       IPS_REQUIRE(n_rows == 0 || (c.d_data && aligned16(c.d_data)),
                   "ips_eval_program: column %d: data NULL or misaligned", nd.column);
-      ProgLeaf& lf = prog.leaves[prog.n_leaves];
-      lf.data = c.d_data;
-      lf.encoding = c.encoding;
-      lf.bit_width = c.bit_width;
-      lf.type = c.type;
-      lf.op = nd.op;
-      lf.n_consts = nd.n_consts;
       if (c.encoding == IPS_COL_FLE) {
         IPS_REQUIRE(c.bit_width >= 1 && c.bit_width <= 32, "ips_eval_program: column %d: bit width", nd.column);
         const uint64_t limit = c.bit_width == 32 ? 0xFFFFFFFFull : ((1ull << c.bit_width) - 1ull);
@@ -259,13 +390,45 @@ extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const
         IPS_REQUIRE(c.encoding == IPS_COL_PLAIN, "ips_eval_program: column %d: bad encoding", nd.column);
         IPS_REQUIRE(c.type >= IPS_T_INT8 && c.type <= IPS_T_DOUBLE, "ips_eval_program: column %d: bad type", nd.column);
       }
-      for (int j = 0; j < nd.n_consts; ++j) lf.consts[j] = nd.consts[j];
-      prog.leaf[i] = (int8_t)prog.n_leaves++;
+      desc.encoding = (int8_t)c.encoding;
+      desc.type = (int8_t)c.type;
+      desc.op = (int8_t)nd.op;
+      desc.n_consts = (int8_t)nd.n_consts;
+      desc.bit_width = (int8_t)c.bit_width;
+      desc.leaf_fuse = (int8_t)n_leaves;
+      if (depth >= 1 && i + 1 < n_nodes &&
+          (nodes[i + 1].kind == IPS_NODE_AND || nodes[i + 1].kind == IPS_NODE_OR))
+        desc.leaf_fuse = (int8_t)(n_leaves | ((nodes[i + 1].kind == IPS_NODE_AND ? 1 : 2) << 4));
+      desc.const_lo = (uint32_t)nd.consts[0];
+      desc.const_hi = (uint32_t)(nd.consts[0] >> 32);
+      for (int j = 0; j < nd.n_consts; ++j) prog.consts[n_leaves][j] = nd.consts[j];
+      // staging jobs: a leaf on the column the previous leaf staged re-uses the LDS image
+      const bool wide = c.encoding == IPS_COL_PLAIN && (c.type == IPS_T_INT64 || c.type == IPS_T_DOUBLE);
+      if (!wide && last_staged == c.d_data) {
+        desc.n_stage = 0;
+      } else {
+        desc.n_stage = wide ? 2 : 1;
+        JobDesc& jb = prog.jobs[prog.n_jobs++];
+        jb.data = c.d_data;
+        const int jkind = c.encoding == IPS_COL_FLE ? kJobFle : wide ? kJobPlain8Lo : kJobPlain4;
+        jb.kind_width = jkind | (c.bit_width << 8);
+        jb.inv_width = c.encoding == IPS_COL_FLE ? (uint32_t)(0x100000000ull / (uint64_t)c.bit_width) + 1u : 0u;
+        if (wide) {
+          JobDesc& hi = prog.jobs[prog.n_jobs++];
+          hi = jb;
+          hi.kind_width = kJobPlain8Hi;
+        }
+        last_staged = wide ? nullptr : c.d_data;
+      }
+      ++n_leaves;
       ++depth;
     } else {
       IPS_REQUIRE(nd.kind == IPS_NODE_AND || nd.kind == IPS_NODE_OR, "ips_eval_program: node %d: bad kind", i);
       IPS_REQUIRE(depth >= 2, "ips_eval_program: node %d: stack underflow", i);
       --depth;
+      // folded into the leaf right before it?  (the kernel then skips this node)
+      if (i > 0 && nodes[i - 1].kind == IPS_NODE_LEAF && (prog.nodes[i - 1].leaf_fuse >> 4) != 0)
+        desc.kind = 3;
     }
     if (depth > max_depth) max_depth = depth;
   }
