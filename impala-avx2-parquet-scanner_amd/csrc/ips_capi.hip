@@ -92,8 +92,6 @@ int grid_for_tiles(const void* kernel, int64_t tiles) {
   ips_status launch_fle_encode_part_##P(int, int, const void*, int64_t, uint64_t*, hipStream_t);
 IPS_DECL_PARTS(a) IPS_DECL_PARTS(b) IPS_DECL_PARTS(c) IPS_DECL_PARTS(d)
 
-ips_status launch_plain_pred(int type, const void* page, int64_t n_rows, int op,
-                             const void* literals, int n_literals, uint64_t* bitmap, hipStream_t s);
 ips_status launch_bitmap_binop(int op, uint64_t* a, const uint64_t* b, int64_t n_words, hipStream_t s);
 ips_status launch_bitmap_fill(uint64_t* a, int64_t n_rows, int value, hipStream_t s);
 ips_status launch_bitmap_count(const uint64_t* a, int64_t n_rows, int64_t* count, hipStream_t s);

@@ -33,6 +33,11 @@ constexpr int kThreads = kWave * kWavesPerBlock;
 struct PredArgs {
   int32_t op;        // ips_op
   int32_t n_consts;  // 1, or 1..256 for IN
+  // predicate-only kernels (used by the conjunct-chain strategy of ips_eval_program):
+  int32_t combine;   // 0: bitmap = result; 1: bitmap &= result; 2: bitmap |= result
+  int32_t join;      // 0: single predicate; 1 / 2: result = pred(op, consts[0]) AND / OR
+  int32_t op2;       //    pred(op2, const2), both evaluated in ONE pass over the planes
+  uint32_t const2;   //    (BETWEEN = Ge AND Le arrives this way)
   uint32_t consts[256];
 };
 
@@ -149,6 +154,29 @@ __device__ __forceinline__ uint32_t pred_single_from_lds(const uint32_t* lds32, 
   return cmp_select(s, op);
 }
 
+// Two comparisons against the same column in one pass over its planes (a BETWEEN).
+__device__ __forceinline__ void pred_pair_from_lds(const uint32_t* lds32, int w, int lane, int op1,
+                                                   uint32_t c1, int op2, uint32_t c2,
+                                                   uint32_t* r1, uint32_t* r2) {
+  const uint32_t* p = lds32 + plane_base_dw(w, lane);
+  CmpState s1{0u, ~0u}, s2{0u, ~0u};
+  int k = w - 1;
+  for (; k >= 3; k -= 4) {
+    uint32_t x3 = p[2 * k], x2 = p[2 * k - 2], x1 = p[2 * k - 4], x0 = p[2 * k - 6];
+    cmp_step(s1, x3, bit_mask(c1, k));     cmp_step(s2, x3, bit_mask(c2, k));
+    cmp_step(s1, x2, bit_mask(c1, k - 1)); cmp_step(s2, x2, bit_mask(c2, k - 1));
+    cmp_step(s1, x1, bit_mask(c1, k - 2)); cmp_step(s2, x1, bit_mask(c2, k - 2));
+    cmp_step(s1, x0, bit_mask(c1, k - 3)); cmp_step(s2, x0, bit_mask(c2, k - 3));
+  }
+  for (; k >= 0; --k) {
+    uint32_t x = p[2 * k];
+    cmp_step(s1, x, bit_mask(c1, k));
+    cmp_step(s2, x, bit_mask(c2, k));
+  }
+  *r1 = cmp_select(s1, op1);
+  *r2 = cmp_select(s2, op2);
+}
+
 // IN: the planes are re-read from LDS once per constant, never from HBM (the reference makes K
 // full passes over the block's words as well, fle-encoding.h:8283-8290).
 template <typename ConstsPtrT>
@@ -176,6 +204,11 @@ __device__ __forceinline__ uint32_t pred_in_from_lds(const uint32_t* lds32, int 
 
 __device__ __forceinline__ uint32_t pred_from_lds(const uint32_t* lds32, int w, int lane,
                                                   const PredArgs& a) {
+  if (a.join != 0) {
+    uint32_t r1, r2;
+    pred_pair_from_lds(lds32, w, lane, a.op, a.consts[0], a.op2, a.const2, &r1, &r2);
+    return a.join == 1 ? (r1 & r2) : (r1 | r2);
+  }
   if (a.op != 5) return pred_single_from_lds(lds32, w, lane, a.op, a.consts[0]);
   return pred_in_from_lds(lds32, w, lane, a.consts, a.n_consts);
 }

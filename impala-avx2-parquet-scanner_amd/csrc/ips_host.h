@@ -47,5 +47,11 @@ ips_status launch_fle_encode(int w, int in_width, const void* values, int64_t n_
                              uint64_t* enc, hipStream_t s);
 ips_status launch_fle_pred(int w, const uint64_t* enc, int64_t n_rows, const PredArgs& args,
                            uint32_t* bitmap32, hipStream_t s);
+// combine: 0 set / 1 and-into / 2 or-into the bitmap; join/op2/literal2: second predicate on the
+// same column evaluated in the same pass (0 = none)
+ips_status launch_plain_pred(int type, const void* page, int64_t n_rows, int op,
+                             const void* literals, int n_literals, uint64_t* bitmap, hipStream_t s,
+                             int combine = 0, int join = 0, int op2 = 0,
+                             const void* literal2 = nullptr);
 
 }  // namespace ips

@@ -32,7 +32,11 @@ __global__ __launch_bounds__(kThreads) void fle_pred_kernel(const uint64_t* __re
     wave_lds_fence();
     uint32_t bm = finish_bitmap_dword(pred_from_lds(lds32, w, lane, args), tile, lane, n_rows);
     const int64_t d = tile * 64 + lane;
-    if (d < bm_dwords) bitmap32[d] = bm;
+    if (d < bm_dwords) {
+      if (args.combine == 1) bm &= bitmap32[d];
+      else if (args.combine == 2) bm |= bitmap32[d];
+      bitmap32[d] = bm;
+    }
     wave_lds_fence();
     tile = next;
   }
@@ -63,6 +67,10 @@ template <typename T>
 struct PlainLit {
   T v[16];
   int32_t n;
+  int32_t combine;  // 0 set, 1 and-into, 2 or-into the bitmap
+  int32_t join;     // 0 none; 1 / 2: AND / OR with (x op2 v2) in the same pass
+  int32_t op2;
+  T v2;
 };
 
 template <typename T>
@@ -119,7 +127,16 @@ __global__ __launch_bounds__(kThreads) void plain_pred_kernel(const S* __restric
     uint64_t m[RPL];
 #pragma unroll
     for (int e = 0; e < RPL; ++e) {
-      bool b = (row0 + e < n_rows) && plain_cmp<T>(slot_value<T, S>(raw[e]), op, lit);
+      const T x = slot_value<T, S>(raw[e]);
+      bool b = plain_cmp<T>(x, op, lit);
+      if (lit.join != 0) {
+        PlainLit<T> l2;
+        l2.v[0] = lit.v2;
+        l2.n = 1;
+        const bool b2 = plain_cmp<T>(x, lit.op2, l2);
+        b = lit.join == 1 ? (b && b2) : (b || b2);
+      }
+      b = b && (row0 + e < n_rows);
       m[e] = __builtin_amdgcn_ballot_w64(b);  // bit l <-> row RPL*l + e of the chunk
     }
     // row 64*j + t of the chunk sits in ballot (t % RPL) at bit (64*j + t) / RPL
@@ -134,15 +151,24 @@ __global__ __launch_bounds__(kThreads) void plain_pred_kernel(const S* __restric
       if (lane == j) mine = word;
     }
     const int64_t wi = chunk * RPL + lane;
-    if (lane < RPL && wi < n_words) bitmap[wi] = mine;
+    if (lane < RPL && wi < n_words) {
+      if (lit.combine == 1) mine &= bitmap[wi];
+      else if (lit.combine == 2) mine |= bitmap[wi];
+      bitmap[wi] = mine;
+    }
   }
 }
 
 template <typename T, typename S>
 static ips_status launch_plain_t(const void* page, int64_t n_rows, int op, const void* literals,
-                                 int n_literals, uint64_t* bitmap, hipStream_t s) {
+                                 int n_literals, uint64_t* bitmap, hipStream_t s, int combine,
+                                 int join, int op2, const void* literal2) {
   PlainLit<T> lit;
   lit.n = n_literals;
+  lit.combine = combine;
+  lit.join = join;
+  lit.op2 = op2;
+  lit.v2 = literal2 ? *reinterpret_cast<const T*>(literal2) : T();
   for (int i = 0; i < 16; ++i) lit.v[i] = i < n_literals ? reinterpret_cast<const T*>(literals)[i] : T();
   constexpr int RPL = 16 / sizeof(S);
   int64_t chunks = (n_rows + 64 * RPL - 1) / (64 * RPL);
@@ -158,15 +184,18 @@ static ips_status launch_plain_t(const void* page, int64_t n_rows, int op, const
 
 ips_status launch_plain_pred(int type, const void* page, int64_t n_rows, int op,
                              const void* literals, int n_literals, uint64_t* bitmap,
-                             hipStream_t s) {
+                             hipStream_t s, int combine, int join, int op2, const void* literal2) {
+#define IPS_PL(T, S) \
+  return launch_plain_t<T, S>(page, n_rows, op, literals, n_literals, bitmap, s, combine, join, op2, literal2)
   switch (type) {
-    case IPS_T_INT8: return launch_plain_t<int8_t, int32_t>(page, n_rows, op, literals, n_literals, bitmap, s);
-    case IPS_T_INT16: return launch_plain_t<int16_t, int32_t>(page, n_rows, op, literals, n_literals, bitmap, s);
-    case IPS_T_INT32: return launch_plain_t<int32_t, int32_t>(page, n_rows, op, literals, n_literals, bitmap, s);
-    case IPS_T_INT64: return launch_plain_t<int64_t, int64_t>(page, n_rows, op, literals, n_literals, bitmap, s);
-    case IPS_T_FLOAT: return launch_plain_t<float, int32_t>(page, n_rows, op, literals, n_literals, bitmap, s);
-    case IPS_T_DOUBLE: return launch_plain_t<double, int64_t>(page, n_rows, op, literals, n_literals, bitmap, s);
+    case IPS_T_INT8: IPS_PL(int8_t, int32_t);
+    case IPS_T_INT16: IPS_PL(int16_t, int32_t);
+    case IPS_T_INT32: IPS_PL(int32_t, int32_t);
+    case IPS_T_INT64: IPS_PL(int64_t, int64_t);
+    case IPS_T_FLOAT: IPS_PL(float, int32_t);
+    case IPS_T_DOUBLE: IPS_PL(double, int64_t);
   }
+#undef IPS_PL
   set_error("plain_pred: bad type %d", type);
   return IPS_ERR_INVALID_ARG;
 }

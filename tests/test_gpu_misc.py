@@ -176,9 +176,16 @@ def test_nullable_dictionary_column(capi, O):
     dd.close()
 
 
-def test_fused_program(capi, O):
-    """EvalSimplePredicates over several columns in one launch vs node-by-node oracle evaluation:
-    BETWEEN = And(Ge, Le); And(Gt a, Lt b); Or; IN; PLAIN leaves (int32, int64, double)."""
+@pytest.mark.parametrize("strategy", ["auto", "general"])
+def test_fused_program(capi, O, strategy, monkeypatch):
+    """EvalSimplePredicates over several columns vs numpy: BETWEEN = And(Ge, Le); And(Gt a, Lt b);
+    Or; IN; PLAIN leaves (int32, int64, double).  'auto' lets ips_eval_program use the
+    conjunct-chain strategy where the tree is a chain; 'general' forces the one-launch
+    program kernel for every tree."""
+    if strategy == "general":
+        monkeypatch.setenv("IPS_PROGRAM_NO_CHAIN", "1")
+    else:
+        monkeypatch.delenv("IPS_PROGRAM_NO_CHAIN", raising=False)
     rng = np.random.default_rng(23)
     for n in (1, 2047, 2049, 50021):
         c0 = rng.integers(0, 1 << 12, n).astype(np.uint32)
@@ -210,6 +217,18 @@ def test_fused_program(capi, O):
                  PL(5, O.OP_LT, np.float64(-3.5), O.T_DOUBLE), OR()]
         got = bits_of(words(capi.eval_program(nodes, cols, n)), n)
         exp = (((p32 > 100) | (p64 <= 0)) & np.isin(c1, [1, 9, 15])) | (pf64 < -3.5)
+        assert np.array_equal(got, exp), n
+        # (A and B) or (C and D): needs two live bitmaps -> always the general kernel
+        nodes = [L(0, O.OP_LT, 2000), PL(3, O.OP_GE, np.int32(0), O.T_INT32), AND(),
+                 L(2, O.OP_GE, 1 << 19), PL(4, O.OP_LT, np.int64(5), O.T_INT64), AND(), OR()]
+        got = bits_of(words(capi.eval_program(nodes, cols, n)), n)
+        exp = ((c0 < 2000) & (p32 >= 0)) | ((c2 >= (1 << 19)) & (p64 < 5))
+        assert np.array_equal(got, exp), n
+        # BETWEEN on a PLAIN column + OR-chain
+        nodes = [PL(5, O.OP_GE, np.float64(-1.0), O.T_DOUBLE), PL(5, O.OP_LE, np.float64(2.5), O.T_DOUBLE),
+                 AND(), L(1, O.OP_EQ, 3), OR(), PL(3, O.OP_EQ, np.int32(p32[0]), O.T_INT32), OR()]
+        got = bits_of(words(capi.eval_program(nodes, cols, n)), n)
+        exp = ((pf64 >= -1.0) & (pf64 <= 2.5)) | (c1 == 3) | (p32 == p32[0])
         assert np.array_equal(got, exp), n
         # a single leaf equals ips_fle_pred
         nodes = [L(2, O.OP_EQ, int(c2[0]))]
