@@ -36,9 +36,9 @@ SYMBOLS = [
     "ips_malloc", "ips_free", "ips_memcpy_h2d", "ips_memcpy_d2h", "ips_memset",
     "ips_stream_create", "ips_stream_destroy", "ips_stream_synchronize",
     "ips_fle_encoded_bytes", "ips_fle_encode", "ips_fle_decode", "ips_fle_pred", "ips_fle_scan",
-    "ips_fle_select", "ips_batches_workspace_bytes", "ips_batches_compact",
+    "ips_fle_select", "ips_batches_workspace_bytes", "ips_batches_compact", "ips_assemble_tuples",
     "ips_dict_open", "ips_dict_close", "ips_dict_num_entries", "ips_dict_bit_width",
-    "ips_dict_translate", "ips_dict_pred", "ips_dict_decode", "ips_dict_scan",
+    "ips_dict_translate", "ips_dict_pred", "ips_dict_decode", "ips_dict_scan", "ips_dict_select",
     "ips_plain_stride", "ips_plain_pred",
     "ips_bitmap_and", "ips_bitmap_or", "ips_bitmap_fill", "ips_bitmap_count",
     "ips_expand_workspace_bytes", "ips_bitmap_expand",
@@ -55,6 +55,11 @@ class IpsError(RuntimeError):
 class Column(C.Structure):
     _fields_ = [("encoding", C.c_int32), ("bit_width", C.c_int32), ("type", C.c_int32),
                 ("reserved", C.c_int32), ("d_data", C.c_void_p)]
+
+
+class TupleColumn(C.Structure):
+    _fields_ = [("d_batch_values", C.c_void_p), ("value_width", C.c_int32),
+                ("tuple_offset", C.c_int32)]
 
 
 class Node(C.Structure):
@@ -203,6 +208,25 @@ def batches_compact(bvals, counts, n_rows, stream=None):
     return dense[:int(total.item())]
 
 
+def assemble_tuples(columns, counts, n_rows, tuple_size, stream=None):
+    """columns: list of (batch_values tensor, tuple_offset) sharing 'counts'.  Returns a uint8
+    tensor [n_tuples, tuple_size] of row-major tuples in row order (untouched bytes are zero)."""
+    dev = counts.device
+    arr = (TupleColumn * len(columns))()
+    for i, (bv, off) in enumerate(columns):
+        arr[i].d_batch_values = bv.data_ptr()
+        arr[i].value_width = bv.element_size()
+        arr[i].tuple_offset = off
+    ws = torch.empty(max(int(lib().ips_batches_workspace_bytes(n_rows)), 16), dtype=torch.uint8, device=dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    cap = int(counts.to(torch.int64).sum().item())
+    tuples = torch.zeros(max(cap, 1) * tuple_size, dtype=torch.uint8, device=dev)
+    _ck(lib().ips_assemble_tuples(arr, len(columns), _ptr(counts), C.c_int64(n_rows), tuple_size,
+                                  _ptr(tuples), _ptr(total), _ptr(ws), _stream(stream)))
+    n = int(total.item())
+    return tuples[:n * tuple_size].view(n, tuple_size)
+
+
 # ---- dictionary -----------------------------------------------------------------------------
 class Dict:
     """ips_dict handle (DictDecoder<T>, dict-encoding.h:202-232)."""
@@ -262,6 +286,16 @@ class Dict:
         _ck(lib().ips_dict_scan(self.h, _ptr(codes_enc), C.c_int64(n_rows), bw, op, p, k,
                                 _ptr(bitmap), _ptr(bvals), _ptr(counts), _stream(stream)))
         return bitmap[:_words(n_rows)], bvals, counts[:n_batches(n_rows)]
+
+
+def _dict_select(self, codes_enc, n_rows, bw, bitmap, stream=None):
+    _, bvals, counts = alloc_scan_outputs(n_rows, codes_enc.device, TORCH_SLOT[self.type])
+    _ck(lib().ips_dict_select(self.h, _ptr(codes_enc), C.c_int64(n_rows), bw, _ptr(bitmap),
+                              _ptr(bvals), _ptr(counts), _stream(stream)))
+    return bvals, counts[:n_batches(n_rows)]
+
+
+Dict.select = _dict_select
 
 
 def dict_bit_width(num_entries):

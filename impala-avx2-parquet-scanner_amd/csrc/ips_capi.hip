@@ -100,6 +100,9 @@ ips_status launch_bitmap_expand(const uint64_t* root, const uint64_t* sub, int64
 ips_status launch_batches_compact(const void* batch_values, const uint32_t* counts,
                                   int64_t n_batches, int value_width, void* dense, int64_t* total,
                                   void* workspace, hipStream_t s);
+ips_status launch_assemble_tuples(const ips_tuple_column* cols, int n_cols, const uint32_t* counts,
+                                  int64_t n_batches, int tuple_size, void* tuples, int64_t* total,
+                                  void* workspace, hipStream_t s);
 ips_status launch_synth(uint64_t seed, int64_t n, uint32_t mask, uint32_t* out, hipStream_t s);
 size_t scan_workspace_bytes(int64_t items);
 
@@ -350,6 +353,24 @@ ips_status ips_batches_compact(const void* d_batch_values, const uint32_t* d_bat
                                 d_dense, d_total, d_workspace, S(stream));
 }
 
+ips_status ips_assemble_tuples(const ips_tuple_column* cols, int n_cols,
+                               const uint32_t* d_batch_counts, int64_t n_rows, int tuple_size,
+                               void* d_tuples, int64_t* d_total, void* d_workspace,
+                               ips_stream stream) {
+  IPS_REQUIRE(cols && n_cols >= 1 && n_cols <= IPS_TUPLE_MAX_COLS, "ips_assemble_tuples: n_cols %d not in 1..%d", n_cols, IPS_TUPLE_MAX_COLS);
+  IPS_REQUIRE(n_rows >= 0 && tuple_size > 0, "ips_assemble_tuples: bad n_rows / tuple_size");
+  IPS_REQUIRE(d_total && d_workspace, "ips_assemble_tuples: NULL total/workspace");
+  IPS_REQUIRE(n_rows == 0 || (d_batch_counts && d_tuples), "ips_assemble_tuples: NULL argument");
+  for (int i = 0; i < n_cols; ++i) {
+    IPS_REQUIRE(cols[i].value_width == 4 || cols[i].value_width == 8, "ips_assemble_tuples: column %d: value_width", i);
+    IPS_REQUIRE(cols[i].tuple_offset >= 0 && cols[i].tuple_offset + cols[i].value_width <= tuple_size,
+                "ips_assemble_tuples: column %d: slot outside the tuple", i);
+    IPS_REQUIRE(n_rows == 0 || cols[i].d_batch_values, "ips_assemble_tuples: column %d: NULL values", i);
+  }
+  return launch_assemble_tuples(cols, n_cols, d_batch_counts, n_batches_of(n_rows), tuple_size,
+                                d_tuples, d_total, d_workspace, S(stream));
+}
+
 // ---- dictionary -----------------------------------------------------------------------------
 }  // extern "C"
 
@@ -569,6 +590,23 @@ ips_status ips_dict_scan(const ips_dict* dict, const void* d_codes_enc, int64_t 
   return scan_common(d_codes_enc, n_rows, bit_width, args, ck, d_bitmap, d_batch_values,
                      d_batch_counts, dict->slot, dict->d_entries, (uint32_t)dict->n, nullptr,
                      S(stream));
+}
+
+ips_status ips_dict_select(const ips_dict* dict, const void* d_codes_enc, int64_t n_rows,
+                           int bit_width, const uint64_t* d_bitmap, void* d_batch_values,
+                           uint32_t* d_batch_counts, ips_stream stream) {
+  IPS_REQUIRE(dict != nullptr, "ips_dict_select: NULL dictionary");
+  if (!check_fle_common(d_codes_enc, n_rows, bit_width, "ips_dict_select")) return IPS_ERR_INVALID_ARG;
+  IPS_REQUIRE(bit_width <= 16, "ips_dict_select: code width %d > 16", bit_width);
+  IPS_REQUIRE(n_rows == 0 || (d_bitmap && d_batch_values && aligned16(d_batch_values) && d_batch_counts),
+              "ips_dict_select: NULL or misaligned argument");
+  if (n_rows == 0) return IPS_OK;
+  PredArgs args;
+  memset(&args, 0, sizeof(args));
+  return launch_fle_scan(bit_width, kScanGivenBitmap, dict->slot,
+                         reinterpret_cast<const uint64_t*>(d_codes_enc), n_rows, args, nullptr,
+                         reinterpret_cast<const uint32_t*>(d_bitmap), d_batch_values,
+                         d_batch_counts, dict->d_entries, (uint32_t)dict->n, nullptr, S(stream));
 }
 
 // ---- PLAIN ----------------------------------------------------------------------------------

@@ -1,6 +1,8 @@
 // ips_misc.hip -- the kernels that are not templated on the bit width: predicate-only FLE scan
 // (any w at run time), PLAIN-page predicates, bitmap algebra, IntersectBitset expand, batch
 // concatenation and the synthetic-column generator.  All HBM-bound streaming kernels.
+#include <string.h>
+
 #include "ips_host.h"
 
 namespace ips {
@@ -482,6 +484,87 @@ ips_status launch_batches_compact(const void* batch_values, const uint32_t* coun
     hipLaunchKernelGGL((batches_compact_kernel<uint64_t>), dim3((unsigned)nb), dim3(kScanThreads),
                        0, s, reinterpret_cast<const uint64_t*>(batch_values), counts, n_batches,
                        totals, reinterpret_cast<uint64_t*>(dense));
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+// ---- tuple assembly -------------------------------------------------------------------------
+struct TupleCols {
+  const void* values[IPS_TUPLE_MAX_COLS];
+  int32_t width[IPS_TUPLE_MAX_COLS];
+  int32_t offset[IPS_TUPLE_MAX_COLS];
+  int32_t n_cols;
+  int32_t tuple_size;
+};
+
+// Row-major tuples from per-column batches (AssembleRows, hdfs-parquet-scanner.cc:1151-1181).
+// One wave per batch; lane i handles tuple i, i+64, ... of the batch and writes each column's
+// slot; the batch's first tuple index comes from the block scan of the counts.
+__global__ __launch_bounds__(kScanThreads) void assemble_tuples_kernel(
+    TupleCols tc, const uint32_t* __restrict__ counts, int64_t n_batches,
+    const uint64_t* __restrict__ block_offsets, uint8_t* __restrict__ tuples) {
+  __shared__ uint64_t offs[kScanItems];
+  const int64_t base = (int64_t)blockIdx.x * kScanItems + (int64_t)threadIdx.x * kScanPerThread;
+  uint32_t c[kScanPerThread];
+  uint32_t v = 0;
+#pragma unroll
+  for (int e = 0; e < kScanPerThread; ++e) {
+    c[e] = base + e < n_batches ? counts[base + e] : 0u;
+    v += c[e];
+  }
+  uint32_t total;
+  uint64_t off = block_offsets[blockIdx.x] + block_exclusive_scan(v, &total);
+#pragma unroll
+  for (int e = 0; e < kScanPerThread; ++e) {
+    offs[threadIdx.x * kScanPerThread + e] = off;
+    off += c[e];
+  }
+  __syncthreads();
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  for (int b = wave; b < kScanItems; b += kScanThreads / kWave) {
+    const int64_t batch = (int64_t)blockIdx.x * kScanItems + b;
+    if (batch >= n_batches) break;
+    const uint32_t cnt = counts[batch];
+    uint8_t* dst = tuples + offs[b] * (uint64_t)tc.tuple_size;
+    for (uint32_t i = lane; i < cnt; i += kWave) {
+      uint8_t* t = dst + (uint64_t)i * tc.tuple_size;
+      for (int col = 0; col < tc.n_cols; ++col) {
+        if (tc.width[col] == 4) {
+          const uint32_t x = reinterpret_cast<const uint32_t*>(tc.values[col])[batch * kRowsPerTile + i];
+          __builtin_memcpy(t + tc.offset[col], &x, 4);
+        } else {
+          const uint64_t x = reinterpret_cast<const uint64_t*>(tc.values[col])[batch * kRowsPerTile + i];
+          __builtin_memcpy(t + tc.offset[col], &x, 8);
+        }
+      }
+    }
+  }
+}
+
+ips_status launch_assemble_tuples(const ips_tuple_column* cols, int n_cols, const uint32_t* counts,
+                                  int64_t n_batches, int tuple_size, void* tuples, int64_t* total,
+                                  void* workspace, hipStream_t s) {
+  if (n_batches <= 0) {
+    IPS_HIP_TRY(hipMemsetAsync(total, 0, 8, s));
+    return IPS_OK;
+  }
+  TupleCols tc;
+  memset(&tc, 0, sizeof(tc));
+  tc.n_cols = n_cols;
+  tc.tuple_size = tuple_size;
+  for (int i = 0; i < n_cols; ++i) {
+    tc.values[i] = cols[i].d_batch_values;
+    tc.width[i] = cols[i].value_width;
+    tc.offset[i] = cols[i].tuple_offset;
+  }
+  const int64_t nb = (n_batches + kScanItems - 1) / kScanItems;
+  uint64_t* totals = reinterpret_cast<uint64_t*>(workspace);
+  hipLaunchKernelGGL((scan_block_totals_kernel<ArrayItems>), dim3((unsigned)nb),
+                     dim3(kScanThreads), 0, s, ArrayItems{counts}, n_batches, totals);
+  hipLaunchKernelGGL(scan_of_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, totals, nb, total);
+  hipLaunchKernelGGL(assemble_tuples_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, s, tc,
+                     counts, n_batches, totals, reinterpret_cast<uint8_t*>(tuples));
   IPS_HIP_TRY(hipGetLastError());
   return IPS_OK;
 }

@@ -140,6 +140,25 @@ ips_status ips_batches_compact(const void* d_batch_values, const uint32_t* d_bat
                                int64_t n_rows, int value_width, void* d_dense, int64_t* d_total,
                                void* d_workspace, ips_stream stream);
 
+/* Multi-column late materialisation into row-major tuples (AssembleRows' vector path,
+ * hdfs-parquet-scanner.cc:1151-1181: per selected row, every column's ReadValue writes its slot
+ * at tuple + slot_desc->tuple_offset(); descriptors.h:60-71, 75-95).  All columns were
+ * materialised against the SAME bitmap (ips_fle_select / ips_dict_scan / ips_fle_scan), so they
+ * share d_batch_counts.  Tuple i (i-th selected row, row order) is written at
+ * d_tuples + i*tuple_size; bytes not covered by a slot are left untouched (InitTuple copies a
+ * template tuple first in the reference).  d_total receives the tuple count.
+ * Workspace: ips_batches_workspace_bytes(n_rows). */
+typedef struct {
+  const void* d_batch_values; /* batches of IPS_BATCH_ROWS slots of value_width bytes */
+  int32_t value_width;        /* 4 or 8 */
+  int32_t tuple_offset;       /* byte offset of the slot inside the tuple */
+} ips_tuple_column;
+#define IPS_TUPLE_MAX_COLS 16
+ips_status ips_assemble_tuples(const ips_tuple_column* cols, int n_cols,
+                               const uint32_t* d_batch_counts, int64_t n_rows, int tuple_size,
+                               void* d_tuples, int64_t* d_total, void* d_workspace,
+                               ips_stream stream);
+
 /* ---- sorted dictionary codec ---------------------------------------------------------------- */
 /* DictDecoder<T>::DictDecoder(dict_buffer, dict_len, fixed_len_size), dict-encoding.h:449-459:
  * PLAIN-decodes the (ascending) dictionary page; keeps a host copy for literal translation and a
@@ -177,6 +196,13 @@ ips_status ips_dict_scan(const ips_dict* dict, const void* d_codes_enc, int64_t 
                          int bit_width, ips_op op, const void* literals, int n_literals,
                          uint64_t* d_bitmap, void* d_batch_values, uint32_t* d_batch_counts,
                          ips_stream stream);
+
+/* Late materialisation of a dictionary column against an existing bitmap: per batch, dict[code]
+ * of the rows whose bit is set (ReadValue(skip) -> DictDecoder::GetValue(value, skip),
+ * hdfs-parquet-scanner.cc:515-531, dict-encoding.h:321-330).  Slots as in ips_dict_scan. */
+ips_status ips_dict_select(const ips_dict* dict, const void* d_codes_enc, int64_t n_rows,
+                           int bit_width, const uint64_t* d_bitmap, void* d_batch_values,
+                           uint32_t* d_batch_counts, ips_stream stream);
 
 /* ---- PLAIN fixed-width pages ---------------------------------------------------------------- */
 /* ParquetPlainEncoder::ByteSize(ColumnType), parquet-common.h:92-117: 4 or 8 */

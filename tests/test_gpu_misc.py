@@ -236,3 +236,36 @@ def test_fused_program(capi, O, strategy, monkeypatch):
                               O.fle_pred(e2, n, 21, O.OP_EQ, int(c2[0])))
     with pytest.raises(capi.IpsError):
         capi.eval_program([capi.and_node()], cols, n)            # stack underflow is an error
+
+
+def test_assemble_tuples(capi, O):
+    """Multi-column late materialisation (AssembleRows' vector path, scanner.cc:1151-1181): three
+    columns selected by one conjunction, written as row-major tuples in row order."""
+    rng = np.random.default_rng(31)
+    n = 30011
+    a = rng.integers(0, 1 << 12, n).astype(np.uint32)             # FLE int32-like
+    d64 = np.sort(rng.choice(np.arange(-10 ** 12, 10 ** 12, 10 ** 7), 500, replace=False)).astype(np.int64)
+    codes = rng.integers(0, 500, n).astype(np.uint32)             # dictionary int64
+    c = rng.integers(0, 1 << 20, n).astype(np.uint32)
+    ea, ec = dev_words(O.fle_encode(a, 12)), dev_words(O.fle_encode(c, 20))
+    bw = capi.dict_bit_width(500)
+    ecodes = dev_words(O.fle_encode(codes, bw))
+    dd = capi.Dict(d64.view(np.uint8), O.T_INT64)
+    # predicate on a and c -> one bitmap; then every column is materialised against it
+    nodes = [capi.leaf(0, O.OP_LT, 1000), capi.leaf(1, O.OP_GE, 1 << 19), capi.and_node()]
+    bm = capi.eval_program(nodes, [capi.fle_column(ea, 12), capi.fle_column(ec, 20)], n)
+    sel = (a < 1000) & (c >= (1 << 19))
+    va, counts = capi.fle_select(ea, n, 12, bm)
+    vc, counts2 = capi.fle_select(ec, n, 20, bm)
+    assert torch.equal(counts, counts2)
+    v64, counts3 = dd.select(ecodes, n, bw, bm)      # dict[code] of the selected rows only
+    assert torch.equal(counts, counts3)
+    tuple_size = 24   # [int32 a @0][pad][int64 d @8][int32 c @16][pad]
+    tuples = capi.assemble_tuples([(va, 0), (v64, 8), (vc, 16)], counts, n, tuple_size)
+    t = tuples.cpu().numpy()
+    assert t.shape == (int(sel.sum()), tuple_size)
+    assert np.array_equal(t[:, 0:4].copy().view(np.uint32).ravel(), a[sel])
+    assert np.array_equal(t[:, 8:16].copy().view(np.int64).ravel(), d64[codes][sel])
+    assert np.array_equal(t[:, 16:20].copy().view(np.uint32).ravel(), c[sel])
+    assert not t[:, 4:8].any() and not t[:, 20:24].any()
+    dd.close()
