@@ -176,6 +176,7 @@ def main():
     # ---- 1M-row single-chunk latency (config 1/2 literally: launch-bound) ---------------------
     n1 = 1 << 20
     lat_us = None
+    graph_us = None
     if n >= n1:
         out1 = capi.alloc_scan_outputs(n1, dev)
         for _ in range(5):
@@ -189,6 +190,30 @@ def main():
         e1.record(stream)
         torch.cuda.synchronize()
         lat_us = e0.elapsed_time(e1) * 1000.0 / reps
+        # the same 50 launches captured once into a hipGraph and replayed (the C-ABI launch path
+        # makes no allocation / synchronisation, so it is capturable)
+        graph_us = None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(stream)
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for _ in range(reps):
+                        capi.fle_scan(enc, n1, bw, capi.OP_LT, c, outputs=out1)
+                g.replay()
+                torch.cuda.synchronize()
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record(side)
+                for _ in range(5):
+                    g.replay()
+                g1.record(side)
+                torch.cuda.synchronize()
+                graph_us = g0.elapsed_time(g1) * 1000.0 / (5 * reps)
+            stream.wait_stream(side)
+        except Exception as ex:  # capture unsupported on this stack: report eager only
+            graph_us = None
+            print(f"bench.py: hipGraph capture skipped: {ex}", file=sys.stderr)
 
     if rank != 0:
         if gather:
@@ -264,7 +289,8 @@ def main():
         },
         "roofline": roofline, "cpu_baseline": cpu,
         "extra": {"check": check, "selected_rows": n_sel,
-                  "latency": {"rows": n1, "us_per_launch_back_to_back": lat_us and round(lat_us, 2)},
+                  "latency": {"rows": n1, "us_per_launch_back_to_back": lat_us and round(lat_us, 2),
+                              "us_per_launch_hipgraph_replay": graph_us and round(graph_us, 2)},
                   "device": capi.device_info()[0]},
     }
     print(json.dumps(out))
