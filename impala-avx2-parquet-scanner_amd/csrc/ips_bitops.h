@@ -103,24 +103,53 @@ IPS_HD void transpose32(uint32_t (&a)[32]) {
   transpose_stage<1, 0x55555555u>(a);
 }
 
+// Narrow columns need fewer stages: with W <= R planes (R = 8 or 16) only the stages J < R are
+// run, on R registers.  Every 32-bit register then behaves as 32/R independent R-bit lanes, and
+// afterwards a[r] holds 32/R values side by side: lane q of a[r] is the value whose plane bits sit
+// at bit position R*q + r.  Cost: 48 VALU ops for R = 8, 112 for R = 16 (256 for the full matrix).
+template <int R>
+IPS_HD void transpose_lanes(uint32_t (&a)[32]) {
+  if (R >= 32) transpose_stage<16, 0x0000FFFFu>(a);
+  if (R >= 16) transpose_stage<8, 0x00FF00FFu>(a);  // only pairs (k, k+8) with k < 8 hold data
+  transpose_stage<4, 0x0F0F0F0Fu>(a);
+  transpose_stage<2, 0x33333333u>(a);
+  transpose_stage<1, 0x55555555u>(a);
+}
+
+template <int W>
+struct LaneWidth { static constexpr int R = W <= 8 ? 8 : W <= 16 ? 16 : 32; };
+
 // Planes -> values for one half-block.  p[0..W) in, v[j] = value of row j (j = 0..31) out.
+// Row j sits at bit position 31-j.
 template <int W>
 IPS_HD void planes_to_values(const uint32_t (&p)[W], uint32_t (&v)[32]) {
+  constexpr int R = LaneWidth<W>::R;
   uint32_t a[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) a[i] = i < W ? p[i] : 0u;
-  transpose32(a);
+  transpose_lanes<R>(a);  // rows >= R of 'a' are zero and stay untouched by the compiler
 #pragma unroll
-  for (int j = 0; j < 32; ++j) v[j] = a[31 - j];
+  for (int j = 0; j < 32; ++j) {
+    const int pos = 31 - j;
+    if (R == 32) v[j] = a[pos];
+    else v[j] = (a[pos % R] >> (R * (pos / R))) & ((1u << R) - 1u);
+  }
 }
 
 // Values -> planes (the encoder direction): v[j] = value of row j, p[i] = plane i bits.
 template <int W>
 IPS_HD void values_to_planes(const uint32_t (&v)[32], uint32_t (&p)[W]) {
+  constexpr int R = LaneWidth<W>::R;
   uint32_t a[32];
 #pragma unroll
-  for (int j = 0; j < 32; ++j) a[31 - j] = v[j];
-  transpose32(a);
+  for (int i = 0; i < 32; ++i) a[i] = 0u;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const int pos = 31 - j;
+    if (R == 32) a[pos] = v[j];
+    else a[pos % R] |= (v[j] & ((1u << R) - 1u)) << (R * (pos / R));
+  }
+  transpose_lanes<R>(a);  // the lane-wise transpose is an involution
 #pragma unroll
   for (int i = 0; i < W; ++i) p[i] = a[i];
 }
