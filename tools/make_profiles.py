@@ -19,7 +19,8 @@ tag = f"round{rnd}"
 
 
 def one(pattern):
-    return glob.glob(os.path.join(src, pattern))[0]
+    # gpurun merges new outputs next to older ones: take the newest match
+    return max(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
 
 
 def largest_scan(rows, grid_key):
