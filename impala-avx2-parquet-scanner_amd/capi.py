@@ -43,6 +43,7 @@ SYMBOLS = [
     "ips_bitmap_and", "ips_bitmap_or", "ips_bitmap_fill", "ips_bitmap_count",
     "ips_expand_workspace_bytes", "ips_bitmap_expand",
     "ips_eval_program", "ips_synth_splitmix_u32",
+    "ips_comm_unique_id", "ips_comm_init", "ips_comm_destroy", "ips_allgather_bitmap",
 ]
 
 
@@ -396,6 +397,35 @@ def eval_program(nodes, cols, n_rows, bitmap=None, device=None, stream=None):
     _ck(lib().ips_eval_program(arr_n, len(nodes), arr_c, len(cols), C.c_int64(n_rows),
                                _ptr(bitmap), _stream(stream)))
     return bitmap[:_words(n_rows)]
+
+
+# ---- multi-GPU exchange (native RCCL path; bench.py uses torch.distributed) -------------------
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _ck(lib().ips_comm_unique_id(buf, COMM_ID_BYTES))
+    return buf.raw
+
+
+class Comm:
+    def __init__(self, id_bytes, nranks, rank):
+        self.h = C.c_void_p(0)
+        self.nranks = nranks
+        _ck(lib().ips_comm_init(C.c_char_p(id_bytes), nranks, rank, C.byref(self.h)))
+
+    def allgather_bitmap(self, local_words, stream=None):
+        out = torch.empty(local_words.numel() * self.nranks, dtype=local_words.dtype,
+                          device=local_words.device)
+        _ck(lib().ips_allgather_bitmap(self.h, _ptr(local_words), C.c_int64(local_words.numel()),
+                                       _ptr(out), _stream(stream)))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().ips_comm_destroy(self.h)
+            self.h = C.c_void_p(0)
 
 
 # ---- synthetic ------------------------------------------------------------------------------

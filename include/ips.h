@@ -255,6 +255,20 @@ typedef struct {
 ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const ips_column* cols, int n_cols,
                             int64_t n_rows, uint64_t* d_bitmap, ips_stream stream);
 
+/* ---- multi-GPU exchange (one process per GPU) ------------------------------------------------ */
+/* The path shards by row stripes (blocks of 64 rows are independent, hdfs-parquet-scanner.cc:
+ * 1056-1060); the only exchange is an all-gather of the stripes' bitmap words: RCCL over xGMI
+ * (ncclAllGather, ncclUint64).  librccl is loaded on first use.  Rank 0 creates the id, the
+ * host's bootstrap distributes its IPS_COMM_ID_BYTES bytes, every rank calls ips_comm_init.
+ * d_all_words receives nranks * n_words words, rank r's slice at r * n_words. */
+#define IPS_COMM_ID_BYTES 128
+typedef struct ips_comm ips_comm;
+ips_status ips_comm_unique_id(void* id_bytes, int len);
+ips_status ips_comm_init(const void* id_bytes, int nranks, int rank, ips_comm** comm);
+ips_status ips_comm_destroy(ips_comm* comm);
+ips_status ips_allgather_bitmap(ips_comm* comm, const uint64_t* d_local_words, int64_t n_words,
+                                uint64_t* d_all_words, ips_stream stream);
+
 /* ---- synthetic data (bench / tests) --------------------------------------------------------- */
 /* d_out[i] = splitmix64(seed + i) & mask, as uint32 (SURVEY 8d generator). */
 ips_status ips_synth_splitmix_u32(uint64_t seed, int64_t n, uint32_t mask, uint32_t* d_out,

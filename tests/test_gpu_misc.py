@@ -269,3 +269,17 @@ def test_assemble_tuples(capi, O):
     assert np.array_equal(t[:, 16:20].copy().view(np.uint32).ravel(), c[sel])
     assert not t[:, 4:8].any() and not t[:, 20:24].any()
     dd.close()
+
+
+def test_native_rccl_allgather_single_rank(capi, O):
+    """ips_allgather_bitmap through librccl (dlopen'ed on first use) with a 1-rank communicator:
+    the gathered words equal the local words.  (N > 1 is exercised by bench.py --gpus N and, for
+    the host logic, by tests/test_distributed_cpu.py.)"""
+    vals = np.arange(10000, dtype=np.uint32) % 97
+    enc = dev_words(O.fle_encode(vals, 7))
+    bm = capi.fle_pred(enc, len(vals), 7, O.OP_LT, 13)
+    comm = capi.Comm(capi.comm_unique_id(), 1, 0)
+    full = comm.allgather_bitmap(bm)
+    torch.cuda.synchronize()
+    assert torch.equal(full, bm)
+    comm.close()
