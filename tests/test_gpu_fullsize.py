@@ -119,3 +119,29 @@ def test_dictionary_int32_in_list_and_gather(capi, ips, O):
         out, bad = dd.decode(enc, n, bw)
         assert int(bad.item()) == 0 and np.array_equal(out.cpu().numpy(), col)
         dd.close()
+
+
+def test_more_than_2_31_rows(capi, ips):
+    """Row indices beyond 32 bits: 2^31 + a ragged tail at w = 2 (encode, predicate, full decode,
+    and the fused scan's bitmap / counts), checked against torch on the raw values."""
+    n, bw = (1 << 31) + 3 * 4097 + 5, 2
+    vals = capi.synth_u32(0x5EED0BB, n, bw)
+    enc = capi.fle_encode(vals, bw)
+    assert enc.numel() == ((n + 63) // 64) * bw
+    bm = capi.fle_pred(enc, n, bw, capi.OP_GE, 2)
+    exp_count = int((vals >= 2).sum().item())
+    assert capi.bitmap_count(bm, n) == exp_count
+    # the ragged tail: the last word has exactly (n % 64) meaningful bits and zero padding
+    tail_bits = n % 64
+    last = int(bm[-1].item()) & 0xFFFFFFFFFFFFFFFF
+    assert last >> tail_bits == 0
+    tail_vals = vals[n - tail_bits:].cpu().numpy()
+    assert last == sum(1 << i for i, v in enumerate(tail_vals) if v >= 2)
+    dec = capi.fle_decode(enc, n, bw, 1)
+    assert torch.equal(dec.to(torch.int32)[-100000:], vals[-100000:])
+    assert int(dec.sum(dtype=torch.int64).item()) == int(vals.sum(dtype=torch.int64).item())
+    del dec
+    # rows on both sides of the 2^31 boundary
+    lo = (1 << 31) - 64
+    bits = torch.tensor([(int(bm[(lo + i) // 64].item()) >> ((lo + i) % 64)) & 1 for i in range(128)])
+    assert torch.equal(bits.bool(), (vals[lo:lo + 128] >= 2).cpu())
