@@ -37,6 +37,7 @@ SYMBOLS = [
     "ips_stream_create", "ips_stream_destroy", "ips_stream_synchronize",
     "ips_fle_encoded_bytes", "ips_fle_encode", "ips_fle_decode", "ips_fle_pred", "ips_fle_scan",
     "ips_fle_select", "ips_batches_workspace_bytes", "ips_batches_compact", "ips_assemble_tuples",
+    "ips_assemble_workspace_bytes", "ips_bitmap_compress",
     "ips_dict_open", "ips_dict_close", "ips_dict_num_entries", "ips_dict_bit_width",
     "ips_dict_translate", "ips_dict_pred", "ips_dict_decode", "ips_dict_scan", "ips_dict_select",
     "ips_plain_stride", "ips_plain_pred",
@@ -60,7 +61,9 @@ class Column(C.Structure):
 
 class TupleColumn(C.Structure):
     _fields_ = [("d_batch_values", C.c_void_p), ("value_width", C.c_int32),
-                ("tuple_offset", C.c_int32)]
+                ("tuple_offset", C.c_int32), ("d_dense_values", C.c_void_p),
+                ("d_nonnull_flags", C.c_void_p), ("null_byte_offset", C.c_int32),
+                ("null_bit_mask", C.c_int32)]
 
 
 class Node(C.Structure):
@@ -210,15 +213,27 @@ def batches_compact(bvals, counts, n_rows, stream=None):
 
 
 def assemble_tuples(columns, counts, n_rows, tuple_size, stream=None):
-    """columns: list of (batch_values tensor, tuple_offset) sharing 'counts'.  Returns a uint8
-    tensor [n_tuples, tuple_size] of row-major tuples in row order (untouched bytes are zero)."""
+    """columns: list of (batch_values tensor, tuple_offset) for REQUIRED columns or
+    (dense_values, tuple_offset, nonnull_flags, null_byte_offset, null_bit_mask) for OPTIONAL
+    ones, all selected by the bitmap behind 'counts'.  Returns a uint8 tensor
+    [n_tuples, tuple_size] of row-major tuples in row order (untouched bytes are zero)."""
     dev = counts.device
     arr = (TupleColumn * len(columns))()
-    for i, (bv, off) in enumerate(columns):
-        arr[i].d_batch_values = bv.data_ptr()
+    n_opt = 0
+    for i, col in enumerate(columns):
+        bv, off = col[0], col[1]
         arr[i].value_width = bv.element_size()
         arr[i].tuple_offset = off
-    ws = torch.empty(max(int(lib().ips_batches_workspace_bytes(n_rows)), 16), dtype=torch.uint8, device=dev)
+        if len(col) > 2:
+            n_opt += 1
+            arr[i].d_dense_values = bv.data_ptr()
+            arr[i].d_nonnull_flags = col[2].data_ptr()
+            arr[i].null_byte_offset, arr[i].null_bit_mask = col[3], col[4]
+        else:
+            arr[i].d_batch_values = bv.data_ptr()
+    lib().ips_assemble_workspace_bytes.restype = C.c_size_t
+    ws = torch.empty(int(lib().ips_assemble_workspace_bytes(C.c_int64(n_rows), n_opt)) + 16,
+                     dtype=torch.uint8, device=dev)
     total = torch.zeros(1, dtype=torch.int64, device=dev)
     cap = int(counts.to(torch.int64).sum().item())
     tuples = torch.zeros(max(cap, 1) * tuple_size, dtype=torch.uint8, device=dev)
@@ -334,6 +349,18 @@ def bitmap_count(a, n_rows, stream=None):
     cnt = torch.zeros(1, dtype=torch.int64, device=a.device)
     _ck(lib().ips_bitmap_count(_ptr(a), C.c_int64(n_rows), _ptr(cnt), _stream(stream)))
     return int(cnt.item())
+
+
+def bitmap_compress(mask, src, n_rows, stream=None):
+    """-> (out words, popcount(mask)): out bit j = src at the j-th set bit of mask."""
+    ws = torch.empty(max(int(lib().ips_expand_workspace_bytes(n_rows)), 16), dtype=torch.uint8,
+                     device=mask.device)
+    out = torch.empty(max(_words(n_rows), 2), dtype=torch.int64, device=mask.device)
+    n_out = torch.zeros(1, dtype=torch.int64, device=mask.device)
+    _ck(lib().ips_bitmap_compress(_ptr(mask), _ptr(src), C.c_int64(n_rows), _ptr(out),
+                                  _ptr(n_out), _ptr(ws), _stream(stream)))
+    k = int(n_out.item())
+    return out[:_words(n_rows)], k
 
 
 def bitmap_expand(root, sub, n_rows, stream=None):

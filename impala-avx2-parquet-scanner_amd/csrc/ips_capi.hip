@@ -105,6 +105,9 @@ ips_status launch_assemble_tuples(const ips_tuple_column* cols, int n_cols, cons
                                   void* workspace, hipStream_t s);
 ips_status launch_synth(uint64_t seed, int64_t n, uint32_t mask, uint32_t* out, hipStream_t s);
 size_t scan_workspace_bytes(int64_t items);
+size_t assemble_workspace_bytes(int64_t n_batches, int n_optional);
+ips_status launch_bitmap_compress(const uint64_t* mask, const uint64_t* src, int64_t n_rows,
+                                  uint64_t* out, int64_t* n_out, void* workspace, hipStream_t s);
 
 ips_status launch_fle_scan(int w, int mode, int gather, const uint64_t* enc, int64_t n_rows,
                            const PredArgs& args, uint32_t* bitmap32, const uint32_t* given32,
@@ -365,10 +368,21 @@ ips_status ips_assemble_tuples(const ips_tuple_column* cols, int n_cols,
     IPS_REQUIRE(cols[i].value_width == 4 || cols[i].value_width == 8, "ips_assemble_tuples: column %d: value_width", i);
     IPS_REQUIRE(cols[i].tuple_offset >= 0 && cols[i].tuple_offset + cols[i].value_width <= tuple_size,
                 "ips_assemble_tuples: column %d: slot outside the tuple", i);
-    IPS_REQUIRE(n_rows == 0 || cols[i].d_batch_values, "ips_assemble_tuples: column %d: NULL values", i);
+    if (cols[i].d_nonnull_flags) {
+      IPS_REQUIRE(cols[i].d_dense_values, "ips_assemble_tuples: column %d: OPTIONAL column without dense values", i);
+      IPS_REQUIRE(cols[i].null_byte_offset >= 0 && cols[i].null_byte_offset < tuple_size &&
+                  cols[i].null_bit_mask > 0 && cols[i].null_bit_mask < 256,
+                  "ips_assemble_tuples: column %d: bad NULL indicator", i);
+    } else {
+      IPS_REQUIRE(n_rows == 0 || cols[i].d_batch_values, "ips_assemble_tuples: column %d: NULL values", i);
+    }
   }
   return launch_assemble_tuples(cols, n_cols, d_batch_counts, n_batches_of(n_rows), tuple_size,
                                 d_tuples, d_total, d_workspace, S(stream));
+}
+
+size_t ips_assemble_workspace_bytes(int64_t n_rows, int n_optional_cols) {
+  return assemble_workspace_bytes(n_batches_of(n_rows), n_optional_cols < 0 ? 0 : n_optional_cols);
 }
 
 // ---- dictionary -----------------------------------------------------------------------------
@@ -660,6 +674,13 @@ ips_status ips_bitmap_count(const uint64_t* d_a, int64_t n_rows, int64_t* d_coun
   return launch_bitmap_count(d_a, n_rows, d_count, S(stream));
 }
 size_t ips_expand_workspace_bytes(int64_t n_rows) { return scan_workspace_bytes((n_rows + 63) / 64); }
+ips_status ips_bitmap_compress(const uint64_t* d_mask, const uint64_t* d_src, int64_t n_rows,
+                               uint64_t* d_out, int64_t* d_n_out, void* d_workspace,
+                               ips_stream stream) {
+  IPS_REQUIRE(n_rows >= 0, "ips_bitmap_compress: n_rows < 0");
+  IPS_REQUIRE(n_rows == 0 || (d_mask && d_src && d_out && d_workspace), "ips_bitmap_compress: NULL argument");
+  return launch_bitmap_compress(d_mask, d_src, n_rows, d_out, d_n_out, d_workspace, S(stream));
+}
 ips_status ips_bitmap_expand(const uint64_t* d_root, const uint64_t* d_sub, int64_t n_rows,
                              uint64_t* d_out, void* d_workspace, ips_stream stream) {
   IPS_REQUIRE(n_rows >= 0, "ips_bitmap_expand: n_rows < 0");

@@ -425,6 +425,93 @@ ips_status launch_bitmap_expand(const uint64_t* root, const uint64_t* sub, int64
   return IPS_OK;
 }
 
+// ---- bitmap compress (inverse of IntersectBitset) ---------------------------------------------
+__device__ __forceinline__ uint64_t extract_bits(uint64_t src, uint64_t mask) {
+  uint64_t out = 0;
+  int j = 0;
+  while (mask) {  // bit j of the result = src at the j-th set bit of mask
+    uint64_t low = mask & (0ull - mask);
+    if (src & low) out |= 1ull << j;
+    ++j;
+    mask ^= low;
+  }
+  return out;
+}
+
+__global__ __launch_bounds__(kScanThreads) void bitmap_compress_kernel(
+    const uint64_t* __restrict__ mask, const uint64_t* __restrict__ src, int64_t n_rows,
+    const uint64_t* __restrict__ block_offsets, unsigned long long* __restrict__ out) {
+  const int64_t n_words = (n_rows + 63) / 64;
+  const int64_t base = (int64_t)blockIdx.x * kScanItems + (int64_t)threadIdx.x * kScanPerThread;
+  PopcItems items{mask, n_rows};
+  uint32_t pc[kScanPerThread];
+  uint32_t v = 0;
+#pragma unroll
+  for (int e = 0; e < kScanPerThread; ++e) {
+    pc[e] = base + e < n_words ? items(base + e) : 0u;
+    v += pc[e];
+  }
+  uint32_t total;
+  uint64_t off = block_offsets[blockIdx.x] + block_exclusive_scan(v, &total);
+#pragma unroll
+  for (int e = 0; e < kScanPerThread; ++e) {
+    if (base + e < n_words && pc[e]) {
+      uint64_t m = mask[base + e];
+      int64_t valid = n_rows - (base + e) * 64;
+      if (valid < 64) m &= (1ull << valid) - 1ull;
+      const uint64_t bits = extract_bits(src[base + e], m);
+      const int sh = (int)(off & 63);
+      if (bits) {  // neighbouring threads share output words: OR the pieces in (out is zeroed)
+        atomicOr(out + (off >> 6), bits << sh);
+        if (sh && (bits >> (64 - sh))) atomicOr(out + (off >> 6) + 1, bits >> (64 - sh));
+      }
+      off += pc[e];
+    }
+  }
+}
+
+ips_status launch_bitmap_compress(const uint64_t* mask, const uint64_t* src, int64_t n_rows,
+                                  uint64_t* out, int64_t* n_out, void* workspace, hipStream_t s) {
+  const int64_t n_words = (n_rows + 63) / 64;
+  if (n_words <= 0) {
+    if (n_out) IPS_HIP_TRY(hipMemsetAsync(n_out, 0, 8, s));
+    return IPS_OK;
+  }
+  IPS_HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_words * 8, s));
+  const int64_t nb = (n_words + kScanItems - 1) / kScanItems;
+  uint64_t* totals = reinterpret_cast<uint64_t*>(workspace);
+  hipLaunchKernelGGL((scan_block_totals_kernel<PopcItems>), dim3((unsigned)nb), dim3(kScanThreads),
+                     0, s, PopcItems{mask, n_rows}, n_words, totals);
+  hipLaunchKernelGGL(scan_of_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, totals, nb, n_out);
+  hipLaunchKernelGGL(bitmap_compress_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, s, mask, src,
+                     n_rows, totals, reinterpret_cast<unsigned long long*>(out));
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+// exclusive prefix popcount per bitmap word (rank support for the NULL flags of selected rows)
+__global__ __launch_bounds__(kScanThreads) void word_prefix_kernel(
+    const uint64_t* __restrict__ words, int64_t n_bits, const uint64_t* __restrict__ block_offsets,
+    uint64_t* __restrict__ prefix) {
+  const int64_t n_words = (n_bits + 63) / 64;
+  const int64_t base = (int64_t)blockIdx.x * kScanItems + (int64_t)threadIdx.x * kScanPerThread;
+  PopcItems items{words, n_bits};
+  uint32_t pc[kScanPerThread];
+  uint32_t v = 0;
+#pragma unroll
+  for (int e = 0; e < kScanPerThread; ++e) {
+    pc[e] = base + e < n_words ? items(base + e) : 0u;
+    v += pc[e];
+  }
+  uint32_t total;
+  uint64_t off = block_offsets[blockIdx.x] + block_exclusive_scan(v, &total);
+#pragma unroll
+  for (int e = 0; e < kScanPerThread; ++e) {
+    if (base + e < n_words) prefix[base + e] = off;
+    off += pc[e];
+  }
+}
+
 size_t scan_workspace_bytes(int64_t items) {
   return (size_t)((items + kScanItems - 1) / kScanItems + 1) * 8;
 }
@@ -490,9 +577,13 @@ ips_status launch_batches_compact(const void* batch_values, const uint32_t* coun
 
 // ---- tuple assembly -------------------------------------------------------------------------
 struct TupleCols {
-  const void* values[IPS_TUPLE_MAX_COLS];
+  const void* values[IPS_TUPLE_MAX_COLS];       // batches (REQUIRED) or dense values (OPTIONAL)
+  const uint64_t* flags[IPS_TUPLE_MAX_COLS];    // OPTIONAL: non-NULL flag per selected row
+  const uint64_t* prefix[IPS_TUPLE_MAX_COLS];   // OPTIONAL: set flags before each flag word
   int32_t width[IPS_TUPLE_MAX_COLS];
   int32_t offset[IPS_TUPLE_MAX_COLS];
+  int32_t null_byte[IPS_TUPLE_MAX_COLS];
+  int32_t null_mask[IPS_TUPLE_MAX_COLS];
   int32_t n_cols;
   int32_t tuple_size;
 };
@@ -529,17 +620,34 @@ __global__ __launch_bounds__(kScanThreads) void assemble_tuples_kernel(
     uint8_t* dst = tuples + offs[b] * (uint64_t)tc.tuple_size;
     for (uint32_t i = lane; i < cnt; i += kWave) {
       uint8_t* t = dst + (uint64_t)i * tc.tuple_size;
+      const uint64_t gi = offs[b] + i;  // index of this tuple among all selected rows
       for (int col = 0; col < tc.n_cols; ++col) {
+        uint64_t src = (uint64_t)batch * kRowsPerTile + i;
+        if (tc.flags[col]) {  // OPTIONAL column: NULL bit, or the rank-th dense value
+          const uint64_t fw = tc.flags[col][gi >> 6];
+          if (!((fw >> (gi & 63)) & 1ull)) {
+            t[tc.null_byte[col]] |= (uint8_t)tc.null_mask[col];
+            continue;
+          }
+          src = tc.prefix[col][gi >> 6] + __builtin_popcountll(fw & ((1ull << (gi & 63)) - 1ull));
+        }
         if (tc.width[col] == 4) {
-          const uint32_t x = reinterpret_cast<const uint32_t*>(tc.values[col])[batch * kRowsPerTile + i];
+          const uint32_t x = reinterpret_cast<const uint32_t*>(tc.values[col])[src];
           __builtin_memcpy(t + tc.offset[col], &x, 4);
         } else {
-          const uint64_t x = reinterpret_cast<const uint64_t*>(tc.values[col])[batch * kRowsPerTile + i];
+          const uint64_t x = reinterpret_cast<const uint64_t*>(tc.values[col])[src];
           __builtin_memcpy(t + tc.offset[col], &x, 8);
         }
       }
     }
   }
+}
+
+size_t scan_workspace_bytes(int64_t items);
+size_t assemble_workspace_bytes(int64_t n_batches, int n_optional) {
+  const int64_t flag_words = (n_batches * kRowsPerTile + 63) / 64;
+  return scan_workspace_bytes(n_batches) +
+         (size_t)n_optional * (scan_workspace_bytes(flag_words) + (size_t)flag_words * 8) + 64;
 }
 
 ips_status launch_assemble_tuples(const ips_tuple_column* cols, int n_cols, const uint32_t* counts,
@@ -553,10 +661,34 @@ ips_status launch_assemble_tuples(const ips_tuple_column* cols, int n_cols, cons
   memset(&tc, 0, sizeof(tc));
   tc.n_cols = n_cols;
   tc.tuple_size = tuple_size;
+  // workspace: [batch scan totals][per OPTIONAL column: flag-word scan totals + per-word prefix]
+  const int64_t n_rows_cap = n_batches * kRowsPerTile;
+  const int64_t flag_words = (n_rows_cap + 63) / 64;
+  uint8_t* ws = reinterpret_cast<uint8_t*>(workspace) + scan_workspace_bytes(n_batches);
   for (int i = 0; i < n_cols; ++i) {
-    tc.values[i] = cols[i].d_batch_values;
     tc.width[i] = cols[i].value_width;
     tc.offset[i] = cols[i].tuple_offset;
+    if (cols[i].d_nonnull_flags) {
+      tc.values[i] = cols[i].d_dense_values;
+      tc.flags[i] = cols[i].d_nonnull_flags;
+      tc.null_byte[i] = cols[i].null_byte_offset;
+      tc.null_mask[i] = cols[i].null_bit_mask;
+      uint64_t* f_totals = reinterpret_cast<uint64_t*>(ws);
+      uint64_t* f_prefix = reinterpret_cast<uint64_t*>(ws + scan_workspace_bytes(flag_words));
+      ws += scan_workspace_bytes(flag_words) + (size_t)flag_words * 8;
+      const int64_t fb = (flag_words + kScanItems - 1) / kScanItems;
+      // the flags bitmap has one bit per selected row; bits beyond the last tuple are zero
+      hipLaunchKernelGGL((scan_block_totals_kernel<PopcItems>), dim3((unsigned)fb),
+                         dim3(kScanThreads), 0, s, PopcItems{tc.flags[i], n_rows_cap}, flag_words,
+                         f_totals);
+      hipLaunchKernelGGL(scan_of_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, f_totals, fb,
+                         (int64_t*)nullptr);
+      hipLaunchKernelGGL(word_prefix_kernel, dim3((unsigned)fb), dim3(kScanThreads), 0, s,
+                         tc.flags[i], n_rows_cap, f_totals, f_prefix);
+      tc.prefix[i] = f_prefix;
+    } else {
+      tc.values[i] = cols[i].d_batch_values;
+    }
   }
   const int64_t nb = (n_batches + kScanItems - 1) / kScanItems;
   uint64_t* totals = reinterpret_cast<uint64_t*>(workspace);

@@ -147,13 +147,24 @@ ips_status ips_batches_compact(const void* d_batch_values, const uint32_t* d_bat
  * share d_batch_counts.  Tuple i (i-th selected row, row order) is written at
  * d_tuples + i*tuple_size; bytes not covered by a slot are left untouched (InitTuple copies a
  * template tuple first in the reference).  d_total receives the tuple count.
- * Workspace: ips_batches_workspace_bytes(n_rows). */
+ * Workspace: ips_assemble_workspace_bytes(n_rows, number of OPTIONAL columns). */
 typedef struct {
   const void* d_batch_values; /* batches of IPS_BATCH_ROWS slots of value_width bytes */
   int32_t value_width;        /* 4 or 8 */
   int32_t tuple_offset;       /* byte offset of the slot inside the tuple */
+  /* OPTIONAL columns (all zero / NULL for REQUIRED ones): d_dense_values holds the values of the
+   * selected NON-NULL rows only, densely, in row order (ips_dict_select over the data rows chosen
+   * by ips_bitmap_compress(nonnull, selection) + ips_batches_compact); d_nonnull_flags has one bit
+   * per selected row (ips_bitmap_compress(selection, nonnull)).  A NULL row gets
+   * tuple[null_byte_offset] |= null_bit_mask (SlotDescriptor::null_indicator_offset(),
+   * descriptors.h:60-71) and its slot is left untouched. */
+  const void* d_dense_values;
+  const uint64_t* d_nonnull_flags;
+  int32_t null_byte_offset;
+  int32_t null_bit_mask;
 } ips_tuple_column;
 #define IPS_TUPLE_MAX_COLS 16
+size_t ips_assemble_workspace_bytes(int64_t n_rows, int n_optional_cols);
 ips_status ips_assemble_tuples(const ips_tuple_column* cols, int n_cols,
                                const uint32_t* d_batch_counts, int64_t n_rows, int tuple_size,
                                void* d_tuples, int64_t* d_total, void* d_workspace,
@@ -227,6 +238,18 @@ ips_status ips_bitmap_count(const uint64_t* d_a, int64_t n_rows, int64_t* d_coun
 size_t ips_expand_workspace_bytes(int64_t n_rows);
 ips_status ips_bitmap_expand(const uint64_t* d_root, const uint64_t* d_sub, int64_t n_rows,
                              uint64_t* d_out, void* d_workspace, ips_stream stream);
+
+/* The inverse of ips_bitmap_expand: d_out bit j = d_src bit (position of the j-th set bit of
+ * d_mask); popcount(mask) bits are produced, the rest of the last word is zero.  With
+ * mask = nonnull, src = selection it yields the selection over a nullable column's DATA rows (the
+ * rows ReadValue really decodes once ReadDefinitionLevel said non-NULL,
+ * hdfs-parquet-scanner.cc:1009-1014); with mask = selection, src = nonnull it yields the
+ * non-NULL flag of every selected row (the NULL indicator bit, :1022-1026).
+ * d_out must hold ceil(n_rows/64) words; d_n_out (int64, may be NULL) receives popcount(mask).
+ * Workspace: ips_expand_workspace_bytes(n_rows). */
+ips_status ips_bitmap_compress(const uint64_t* d_mask, const uint64_t* d_src, int64_t n_rows,
+                               uint64_t* d_out, int64_t* d_n_out, void* d_workspace,
+                               ips_stream stream);
 
 /* ---- fused predicate program (EvalSimplePredicates, hdfs-parquet-scanner.cc:1837-1865) ------ */
 typedef enum { IPS_NODE_LEAF = 0, IPS_NODE_AND = 1, IPS_NODE_OR = 2 } ips_node_kind;
