@@ -38,7 +38,7 @@ SYMBOLS = [
     "ips_fle_encoded_bytes", "ips_fle_encode", "ips_fle_decode", "ips_fle_pred", "ips_fle_scan",
     "ips_fle_select", "ips_batches_workspace_bytes", "ips_batches_compact", "ips_assemble_tuples",
     "ips_assemble_workspace_bytes", "ips_bitmap_compress",
-    "ips_dict_open", "ips_dict_close", "ips_dict_num_entries", "ips_dict_bit_width",
+    "ips_dict_open", "ips_dict_close", "ips_dict_num_entries", "ips_dict_bit_width", "ips_dict_encode",
     "ips_dict_translate", "ips_dict_pred", "ips_dict_decode", "ips_dict_scan", "ips_dict_select",
     "ips_plain_stride", "ips_plain_pred",
     "ips_bitmap_and", "ips_bitmap_or", "ips_bitmap_fill", "ips_bitmap_count",
@@ -312,6 +312,20 @@ def _dict_select(self, codes_enc, n_rows, bw, bitmap, stream=None):
 
 
 Dict.select = _dict_select
+
+
+def dict_encode(values, type_, stream=None):
+    """values: cuda tensor of PLAIN slots (int32/float32/int64/float64).  -> (dictionary page
+    bytes (np.uint8), code bit width, FLE blocks of the codes (int64 words))."""
+    n = values.numel()
+    page = np.zeros(40000 * 8, dtype=np.uint8)
+    dict_len = C.c_int64(0)
+    bw = C.c_int(0)
+    enc = torch.empty(max(fle_encoded_bytes(n, 16) // 8, 2), dtype=torch.int64, device=values.device)
+    _ck(lib().ips_dict_encode(_ptr(values), C.c_int64(n), type_, page.ctypes.data_as(C.c_void_p),
+                              C.c_int64(len(page)), C.byref(dict_len), C.byref(bw), _ptr(enc),
+                              _stream(stream)))
+    return page[:dict_len.value].copy(), bw.value, enc[:fle_encoded_bytes(n, bw.value) // 8]
 
 
 def dict_bit_width(num_entries):

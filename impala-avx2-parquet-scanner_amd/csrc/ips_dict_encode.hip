@@ -1,0 +1,197 @@
+// ips_dict_encode.hip -- dictionary encoder of a column chunk on the GPU:
+// DictEncoder<T>::Put x n (dict-encoding.h:234-274), WriteDict (sort ascending, :393-406) and
+// WriteData (remap to sorted codes + FleEncoder, :408-423).
+//
+// The dictionary is tiny (<= 40000 entries, dict-encoding.h:157) while the column is not, so:
+//   1. one pass over the values inserts their bit patterns into an open-addressing hash table in
+//      HBM (one 64-bit CAS per probe; the reference chains nodes through a 64K-bucket table),
+//   2. the <= 40000 distinct entries go to the host, are sorted with T's operator< (signed ints,
+//      IEEE floats -- what NodeValLess does) and every occupied slot receives its sorted code,
+//   3. a second pass looks every value up again and writes its code; ips_fle_encode bit-slices
+//      the codes with the width ceil(log2 D).
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "ips_host.h"
+
+namespace ips {
+
+constexpr uint32_t kTableSlots = 1u << 17;  // 131072: load factor <= 0.31 at the 40000 cap
+constexpr uint64_t kEmpty = ~0ull;
+constexpr int kMaxEntries = 40000;
+
+__device__ __forceinline__ uint32_t hash64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return (uint32_t)x;
+}
+
+// Key of a PLAIN slot = its low KB bytes: the bytes ParquetPlainEncoder::Decode reads back
+// (parquet-common.h:180-183, :319-322 for int8/int16, whose upper slot bytes are unspecified).
+template <typename S, int KB>
+__device__ __forceinline__ uint64_t slot_bits(const S* values, int64_t i) {
+  const uint64_t raw = sizeof(S) == 4 ? (uint64_t)(uint32_t)values[i] : (uint64_t)values[i];
+  return KB >= 8 ? raw : raw & ((1ull << (KB * 8 % 64)) - 1);
+}
+
+// counters: [0] distinct entries, [1] the all-ones pattern occurred (it is the table's EMPTY mark)
+template <typename S, int KB>
+__global__ void dict_insert_kernel(const S* __restrict__ values, int64_t n,
+                                   unsigned long long* __restrict__ table,
+                                   unsigned int* __restrict__ counters) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t bits = slot_bits<S, KB>(values, i);
+    if (bits == kEmpty) {
+      counters[1] = 1u;
+      continue;
+    }
+    uint32_t h = hash64(bits) & (kTableSlots - 1);
+    for (uint32_t probe = 0; probe < kTableSlots; ++probe) {
+      unsigned long long seen = table[h];
+      if (seen == bits) break;
+      if (seen == kEmpty) {
+        seen = atomicCAS(table + h, (unsigned long long)kEmpty, (unsigned long long)bits);
+        if (seen == kEmpty) {
+          atomicAdd(counters, 1u);
+          break;
+        }
+        if (seen == bits) break;
+      }
+      h = (h + 1) & (kTableSlots - 1);
+      if (counters[0] > (unsigned)kMaxEntries) break;  // over the cap: the caller gives up anyway
+    }
+  }
+}
+
+template <typename S, int KB>
+__global__ void dict_lookup_kernel(const S* __restrict__ values, int64_t n,
+                                   const unsigned long long* __restrict__ table,
+                                   const uint32_t* __restrict__ code_of_slot, uint32_t code_of_ones,
+                                   uint32_t* __restrict__ codes) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t bits = slot_bits<S, KB>(values, i);
+    uint32_t code = code_of_ones;
+    if (bits != kEmpty) {
+      uint32_t h = hash64(bits) & (kTableSlots - 1);
+      while (table[h] != bits) h = (h + 1) & (kTableSlots - 1);  // present by construction
+      code = code_of_slot[h];
+    }
+    codes[i] = code;
+  }
+}
+
+template <typename T>
+static T from_bits(uint64_t bits) {
+  T t;
+  if (sizeof(T) <= 4) { uint32_t lo = (uint32_t)bits; memcpy(&t, &lo, sizeof(T)); }
+  else memcpy(&t, &bits, sizeof(T));
+  return t;
+}
+
+template <typename T, typename S>
+static ips_status dict_encode_t(const void* d_values, int64_t n, ips_type type, void* h_dict_page,
+                                int64_t page_capacity, int64_t* dict_len, int* bit_width,
+                                void* d_codes_enc, hipStream_t s) {
+  unsigned long long* d_table = nullptr;
+  unsigned int* d_counters = nullptr;
+  uint32_t* d_code_of_slot = nullptr;
+  uint32_t* d_codes = nullptr;
+  auto cleanup = [&]() {
+    if (d_table) (void)hipFree(d_table);
+    if (d_counters) (void)hipFree(d_counters);
+    if (d_code_of_slot) (void)hipFree(d_code_of_slot);
+    if (d_codes) (void)hipFree(d_codes);
+  };
+#define IPS_TRY_CLEAN(expr)                                     \
+  do {                                                          \
+    hipError_t _e = (expr);                                     \
+    if (_e != hipSuccess) { cleanup(); return hip_fail(_e, #expr); } \
+  } while (0)
+  IPS_TRY_CLEAN(hipMalloc(&d_table, (size_t)kTableSlots * 8));
+  IPS_TRY_CLEAN(hipMalloc(&d_counters, 8));
+  IPS_TRY_CLEAN(hipMalloc(&d_code_of_slot, (size_t)kTableSlots * 4));
+  IPS_TRY_CLEAN(hipMalloc(&d_codes, (size_t)(n > 0 ? n : 1) * 4 + 16));
+  IPS_TRY_CLEAN(hipMemsetAsync(d_table, 0xFF, (size_t)kTableSlots * 8, s));
+  IPS_TRY_CLEAN(hipMemsetAsync(d_counters, 0, 8, s));
+  const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_cus() * 8);
+  if (n > 0)
+    hipLaunchKernelGGL((dict_insert_kernel<S, (int)sizeof(T)>), dim3(grid > 0 ? grid : 1), dim3(256), 0, s,
+                       reinterpret_cast<const S*>(d_values), n, d_table, d_counters);
+  unsigned int counters[2] = {0, 0};
+  IPS_TRY_CLEAN(hipMemcpyAsync(counters, d_counters, 8, hipMemcpyDeviceToHost, s));
+  IPS_TRY_CLEAN(hipStreamSynchronize(s));
+  const int64_t entries = (int64_t)counters[0] + (counters[1] ? 1 : 0);
+  if (entries > kMaxEntries) {
+    cleanup();
+    set_error("ips_dict_encode: more than %d distinct values (dict-encoding.h:157): use PLAIN", kMaxEntries);
+    return IPS_ERR_UNSUPPORTED;
+  }
+  const int slot = ips_plain_stride(type);
+  if (entries * slot > page_capacity) {
+    cleanup();
+    set_error("ips_dict_encode: dictionary page needs %lld bytes", (long long)(entries * slot));
+    return IPS_ERR_INVALID_ARG;
+  }
+  std::vector<unsigned long long> table(kTableSlots);
+  IPS_TRY_CLEAN(hipMemcpy(table.data(), d_table, (size_t)kTableSlots * 8, hipMemcpyDeviceToHost));
+  struct Entry { T value; uint32_t slot; };
+  std::vector<Entry> ents;
+  ents.reserve((size_t)entries);
+  for (uint32_t h = 0; h < kTableSlots; ++h)
+    if (table[h] != kEmpty) ents.push_back(Entry{from_bits<T>(table[h]), h});
+  if (counters[1]) ents.push_back(Entry{from_bits<T>(kEmpty), kTableSlots});
+  std::sort(ents.begin(), ents.end(), [](const Entry& a, const Entry& b) { return a.value < b.value; });
+  std::vector<uint32_t> code_of_slot(kTableSlots, 0);
+  uint32_t code_of_ones = 0;
+  uint8_t* page = reinterpret_cast<uint8_t*>(h_dict_page);
+  for (size_t i = 0; i < ents.size(); ++i) {
+    if (ents[i].slot == kTableSlots) code_of_ones = (uint32_t)i; else code_of_slot[ents[i].slot] = (uint32_t)i;
+    // ParquetPlainEncoder::Encode: sizeof(T) bytes, int8/int16 widened to the 4-byte slot
+    memset(page + i * slot, 0, (size_t)slot);
+    if (sizeof(T) < 4) { int32_t wide = (int32_t)ents[i].value; memcpy(page + i * slot, &wide, 4); }
+    else memcpy(page + i * slot, &ents[i].value, sizeof(T));
+  }
+  *dict_len = (int64_t)ents.size() * slot;
+  const int bw = ips_dict_bit_width((int64_t)ents.size());
+  *bit_width = bw;
+  ips_status st = IPS_OK;
+  if (n > 0 && bw > 0) {
+    IPS_TRY_CLEAN(hipMemcpyAsync(d_code_of_slot, code_of_slot.data(), (size_t)kTableSlots * 4,
+                                 hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL((dict_lookup_kernel<S, (int)sizeof(T)>), dim3(grid > 0 ? grid : 1), dim3(256), 0, s,
+                       reinterpret_cast<const S*>(d_values), n, d_table, d_code_of_slot, code_of_ones,
+                       d_codes);
+    st = launch_fle_encode(bw, 4, d_codes, n, reinterpret_cast<uint64_t*>(d_codes_enc), s);
+    IPS_TRY_CLEAN(hipStreamSynchronize(s));
+  }
+  cleanup();
+  return st;
+#undef IPS_TRY_CLEAN
+}
+
+}  // namespace ips
+
+using namespace ips;
+
+extern "C" ips_status ips_dict_encode(const void* d_values, int64_t n_rows, ips_type type,
+                                      void* h_dict_page, int64_t dict_page_capacity,
+                                      int64_t* dict_len, int* bit_width, void* d_codes_enc,
+                                      ips_stream stream) {
+  IPS_REQUIRE(n_rows >= 0, "ips_dict_encode: n_rows < 0");
+  IPS_REQUIRE(type >= IPS_T_INT8 && type <= IPS_T_DOUBLE, "ips_dict_encode: bad type %d", (int)type);
+  IPS_REQUIRE(h_dict_page && dict_len && bit_width, "ips_dict_encode: NULL out pointer");
+  IPS_REQUIRE(n_rows == 0 || (d_values && aligned16(d_values) && d_codes_enc && aligned16(d_codes_enc)),
+              "ips_dict_encode: NULL or misaligned device pointer");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (type) {
+    case IPS_T_INT8: return dict_encode_t<int8_t, int32_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, s);
+    case IPS_T_INT16: return dict_encode_t<int16_t, int32_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, s);
+    case IPS_T_INT32: return dict_encode_t<int32_t, int32_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, s);
+    case IPS_T_INT64: return dict_encode_t<int64_t, int64_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, s);
+    case IPS_T_FLOAT: return dict_encode_t<float, int32_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, s);
+    default: return dict_encode_t<double, int64_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, s);
+  }
+}

@@ -151,6 +151,18 @@ static void ValidateDict(const std::vector<T>& values) {
     CHECK(decoder.GetValue(&j));
     CHECK(i == j);
   }
+  // the bulk GPU encoder produces the same two pages byte for byte
+  const int slot = ips_plain_stride(IpsTypeOf<T>::value);
+  std::vector<uint8_t> slots(values.size() * (size_t)slot);
+  for (size_t i = 0; i < values.size(); ++i) ParquetPlainEncoder::Encode(slots.data() + i * slot, -1, values[i]);
+  ips::DeviceBuffer d_slots;
+  CHECK(d_slots.upload(slots.data(), slots.size()));
+  std::vector<uint8_t> gpu_dict, gpu_data;
+  CHECK(DictEncoder<T>::EncodeColumn(d_slots.get(), (int64_t)values.size(), &gpu_dict, &gpu_data));
+  CHECK((int)gpu_dict.size() == encoder.dict_encoded_size());
+  CHECK(memcmp(gpu_dict.data(), dict_buffer.data(), gpu_dict.size()) == 0);
+  CHECK((int)gpu_data.size() == data_len);
+  CHECK(memcmp(gpu_data.data(), data_buffer.data(), (size_t)data_len) == 0);
 }
 
 template <typename T>

@@ -90,6 +90,34 @@ class DictEncoder : public DictEncoderBase {
 
   virtual int num_entries() const { return (int)values_.size(); }
 
+  // Bulk form of Put x n + WriteDict + WriteData for a column chunk that is already on the device
+  // (n PLAIN slots): hashing, remap and bit-slicing run on the GPU (ips_dict_encode).  dict_page
+  // and data_page are resized to the exact page sizes; false = over the 40000-entry cap, in
+  // which case the writer falls back to PLAIN as it does when Put() returns -1.
+  static bool EncodeColumn(const void* d_values, int64_t n, std::vector<uint8_t>* dict_page,
+                           std::vector<uint8_t>* data_page, ips_stream stream = nullptr) {
+    const ips_type type = IpsTypeOf<T>::value;
+    dict_page->assign((size_t)40000 * (size_t)ips_plain_stride(type), 0);
+    ips::DeviceBuffer blocks((size_t)ips_fle_encoded_bytes(n, 16) + 16);
+    int64_t dict_len = 0;
+    int bw = 0;
+    const ips_status st = ips_dict_encode(d_values, n, type, dict_page->data(), (int64_t)dict_page->size(),
+                                          &dict_len, &bw, blocks.get(), stream);
+    if (st == IPS_ERR_UNSUPPORTED) return false;
+    if (!ips::ok(st, "ips_dict_encode")) return false;
+    dict_page->resize((size_t)dict_len);
+    const int64_t len = ips_fle_encoded_bytes(n, bw);
+    data_page->assign((size_t)len + 1, 0);
+    (*data_page)[0] = (uint8_t)bw;
+    if (len > 0 && bw > 0) {
+      std::vector<uint8_t> tmp((size_t)len);
+      if (!ips::ok(ips_memcpy_d2h(tmp.data(), blocks.get(), (size_t)len, stream), "d2h")) return false;
+      if (!ips::ok(ips_stream_synchronize(stream), "sync")) return false;
+      memcpy(data_page->data() + 1, tmp.data(), (size_t)len);
+    }
+    return true;
+  }
+
  private:
   std::vector<T> values_;
   std::map<T, int> index_of_;

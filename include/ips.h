@@ -182,6 +182,20 @@ int64_t ips_dict_num_entries(const ips_dict* dict);
 /* DictEncoderBase::bit_width(), dict-encoding.h:76-80 with BitUtil::Log2, bit-util.h:128-140 */
 int ips_dict_bit_width(int64_t num_entries);
 
+/* Dictionary-encode a column chunk on the GPU: DictEncoder<T>::Put x n, WriteDict (entries sorted
+ * ascending, dict-encoding.h:393-406) and WriteData (indices remapped to sorted codes and
+ * bit-sliced with width ceil(log2 D), :408-423).  d_values: n_rows PLAIN slots (4 or 8 bytes,
+ * ips_plain_stride).  h_dict_page receives the PLAIN dictionary page (*dict_len bytes),
+ * *bit_width the code width (the byte WriteData puts in front of the blocks), d_codes_enc the FLE
+ * blocks (ips_fle_encoded_bytes(n_rows, *bit_width) bytes; reserve width 16).  More than 40000
+ * distinct values (dict-encoding.h:157) -> IPS_ERR_UNSUPPORTED, the caller falls back to PLAIN
+ * like the reference's writer.  Synchronous (the <= 40000 entries are sorted on the host).
+ * int8/int16 values are the low 1/2 bytes of their slot (what Decode reads) and are written to
+ * the page sign-extended to int32; floats are keyed by bit pattern (+0.0 and -0.0 are two entries). */
+ips_status ips_dict_encode(const void* d_values, int64_t n_rows, ips_type type, void* h_dict_page,
+                           int64_t dict_page_capacity, int64_t* dict_len, int* bit_width,
+                           void* d_codes_enc, ips_stream stream);
+
 /* Literal -> code translation of DictDecoder<T>::Eq/Lt/Le/Gt/Ge/In, dict-encoding.h:461-541.
  * literals: n_literals values of the dictionary's type (host).  codes must hold n_literals. */
 ips_status ips_dict_translate(const ips_dict* dict, ips_op op, const void* literals,

@@ -360,8 +360,12 @@ int64_t orc_dict_build(const void* values, int64_t n, int type, void* dict_page,
   int page_sz = (type == ORC_T_INT8 || type == ORC_T_INT16) ? 4 : sz;
   uint8_t* page = (uint8_t*)dict_page;
   for (int64_t i = 0; i < d; ++i) {
-    memset(page + i * page_sz, 0, (size_t)page_sz);
-    memcpy(page + i * page_sz, sorted + i * sz, (size_t)sz);
+    /* parquet-common.h:170-173 copies ByteSize(t) = 4 bytes out of a 1- or 2-byte object, so the
+     * upper bytes of a narrow slot are unspecified in the reference (Decode, :319-322, reads the
+     * low byte(s) only); the restatement writes the value as the int32 Parquet declares. */
+    if (type == ORC_T_INT8) { int32_t wide = *(const int8_t*)(sorted + i * sz); memcpy(page + i * 4, &wide, 4); }
+    else if (type == ORC_T_INT16) { int32_t wide; int16_t v; memcpy(&v, sorted + i * sz, 2); wide = v; memcpy(page + i * 4, &wide, 4); }
+    else memcpy(page + i * page_sz, sorted + i * sz, (size_t)sz);
   }
   free(sorted);
   return d;

@@ -344,3 +344,39 @@ def test_nullable_column_materialisation(capi, O):
     assert np.array_equal(got_opt[~nulls], full[sel_np][~nulls])
     assert not got_opt[nulls].any()                               # NULL slots untouched (zero)
     dd.close()
+
+
+@pytest.mark.parametrize("type_name", TYPES)
+def test_dict_encode_on_gpu(capi, O, type_name):
+    """GPU DictEncoder (Put / WriteDict / WriteData) vs the oracle's sort + remap, and the
+    round trip through the GPU DictDecoder (dict-test.cc's ValidateDict shape)."""
+    t = getattr(O, type_name)
+    rng = np.random.default_rng(70 + t)
+    for n, distinct in ((1, 1), (100, 1), (5000, 300), (200000, 39999 if t not in (O.T_INT8,) else 200)):
+        distinct = min(distinct, 100) if t == O.T_INT8 else distinct
+        vals = make_dict_column(O, t, rng, max(n, distinct), distinct)[:max(n, distinct)]
+        n = len(vals)
+        d_ref, page_ref, codes_ref = O.dict_build(vals, t)
+        slots = O.plain_encode(vals, t)                      # 4- or 8-byte PLAIN slots
+        if t in (O.T_INT8, O.T_INT16):
+            # the reference's writer leaves the upper slot bytes unspecified (parquet-common.h:170)
+            junk = rng.integers(0, 256, len(slots), dtype=np.uint8)
+            keep = np.arange(len(slots)) % 4 < O.NP_TYPES[t]().itemsize
+            slots = np.where(keep, slots, junk).astype(np.uint8)
+        d_slots = torch.from_numpy(np.concatenate([slots, np.zeros(16, np.uint8)])).cuda()
+        page, bw, enc = capi.dict_encode(d_slots[:len(slots)].view(
+            {4: torch.int32, 8: torch.int64}[len(slots) // n]), t)
+        assert np.array_equal(page, page_ref), (type_name, n)
+        assert bw == O.bit_width_for_entries(len(d_ref))
+        if bw:
+            assert np.array_equal(words(enc), O.fle_encode(codes_ref, bw))
+            dd = capi.Dict(page, t)
+            out, bad = dd.decode(enc, n, bw)
+            assert int(bad.item()) == 0
+            assert np.array_equal(out.cpu().numpy().astype(O.NP_TYPES[t]), vals)
+            dd.close()
+    # the 40000-entry cap of the reference
+    if t == O.T_INT32:
+        big = torch.arange(0, 50000, dtype=torch.int32, device="cuda")
+        with pytest.raises(capi.IpsError):
+            capi.dict_encode(big, t)
