@@ -89,7 +89,9 @@ int grid_for_tiles(const void* kernel, int64_t tiles) {
                                       uint32_t, int32_t*, hipStream_t);                         \
   ips_status launch_fle_decode_part_##P(int, int, int, const uint64_t*, int64_t, void*,         \
                                         const void*, uint32_t, int32_t*, hipStream_t);          \
-  ips_status launch_fle_encode_part_##P(int, int, const void*, int64_t, uint64_t*, hipStream_t);
+  ips_status launch_fle_encode_part_##P(int, int, const void*, int64_t, uint64_t*, hipStream_t); \
+  ips_status launch_fle_pred_part_##P(int, const uint64_t*, int64_t, const PredArgs&, uint32_t*, \
+                                      hipStream_t);
 IPS_DECL_PARTS(a) IPS_DECL_PARTS(b) IPS_DECL_PARTS(c) IPS_DECL_PARTS(d)
 
 ips_status launch_bitmap_binop(int op, uint64_t* a, const uint64_t* b, int64_t n_words, hipStream_t s);
@@ -131,6 +133,14 @@ ips_status launch_fle_decode(int w, int out_width, int gather, const uint64_t* e
   if (w <= 24) return launch_fle_decode_part_c(IPS_A);
   return launch_fle_decode_part_d(IPS_A);
 #undef IPS_A
+}
+
+ips_status launch_fle_pred(int w, const uint64_t* enc, int64_t n_rows, const PredArgs& args,
+                           uint32_t* bitmap32, hipStream_t s) {
+  if (w <= 8) return launch_fle_pred_part_a(w, enc, n_rows, args, bitmap32, s);
+  if (w <= 16) return launch_fle_pred_part_b(w, enc, n_rows, args, bitmap32, s);
+  if (w <= 24) return launch_fle_pred_part_c(w, enc, n_rows, args, bitmap32, s);
+  return launch_fle_pred_part_d(w, enc, n_rows, args, bitmap32, s);
 }
 
 ips_status launch_fle_encode(int w, int in_width, const void* values, int64_t n_rows,

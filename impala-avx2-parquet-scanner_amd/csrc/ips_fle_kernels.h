@@ -135,6 +135,61 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kerne
 }
 
 // ---------------------------------------------------------------------------------------------
+// Predicate only: FleDecoder::Eq/Lt/Le/Gt/Ge/In on the encoded planes (fle-encoding.h:7962-8313).
+// Nothing is decoded: per 64 rows the wave reads W words and writes one.  args.combine and-s /
+// or-s the result into the existing bitmap (a conjunct chain touches the bitmap once per conjunct
+// instead of once more for the AND), args.join evaluates a second comparison on the same column
+// in the same pass (BETWEEN).
+// ---------------------------------------------------------------------------------------------
+enum PredKind { kPredSingle = 0, kPredPair = 1, kPredInList = 2 };
+
+template <int W, int KIND>
+__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_w_kernel(
+    const uint64_t* __restrict__ enc, int64_t n_rows, PredArgs args,
+    uint32_t* __restrict__ bitmap32) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * plane_tile_bytes(W) / 4];
+  constexpr int L = (16 * W + kWave - 1) / kWave;
+  const int lane = lane_id();
+  const int wave = wave_id();
+  uint32_t* lds32 = lds_all + wave * (plane_tile_bytes(W) / 4);
+
+  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int64_t total_words = ((n_rows + 63) / 64) * W;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t bm_dwords = bitmap_dwords(n_rows);
+  int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  u32x4 r[L];
+  if (tile < tiles) tile_load<L>(enc, tile, W, total_words, lane, r);
+  while (tile < tiles) {
+    tile_to_lds<L>(lds32, W, lane, r);
+    const int64_t next = tile + stride;
+    if (next < tiles) tile_load<L>(enc, next, W, total_words, lane, r);  // register prefetch
+    wave_lds_fence();
+    uint32_t sel;
+    if (KIND == kPredSingle) {
+      uint32_t p[W];
+      planes_from_lds<W>(lds32, lane, p);
+      sel = pred_from_regs<W>(p, args);
+    } else if (KIND == kPredPair) {
+      uint32_t r1, r2;
+      pred_pair_from_lds(lds32, W, lane, args.op, args.consts[0], args.op2, args.const2, &r1, &r2);
+      sel = args.join == 1 ? (r1 & r2) : (r1 | r2);
+    } else {
+      sel = pred_in_from_lds(lds32, W, lane, args.consts, args.n_consts);
+    }
+    uint32_t bm = finish_bitmap_dword(sel, tile, lane, n_rows);
+    const int64_t d = tile * 64 + lane;
+    if (d < bm_dwords) {
+      if (args.combine == 1) bm &= bitmap32[d];
+      else if (args.combine == 2) bm |= bitmap32[d];
+      bitmap32[d] = bm;
+    }
+    wave_lds_fence();  // LDS region is reused by the next sub-tile
+    tile = next;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Full decode: FleDecoder::Get x n via Unpack_w (fle-encoding.h:404-567, 569-7329), batch form.
 // OW = bytes per stored value (1, 2, 4) when G == 0; with G != 0 every code is looked up in the
 // dictionary and the G-byte entry is stored (DictDecoder::GetValue, dict-encoding.h:310-319).

@@ -76,4 +76,37 @@ ips_status IPS_CAT(launch_fle_scan_part_, IPS_PART)(
   return IPS_ERR_INVALID_ARG;
 }
 
+template <int W, int KIND>
+static ips_status launch_pred_wk(const uint64_t* enc, int64_t n_rows, const PredArgs& args,
+                                 uint32_t* bitmap32, hipStream_t s) {
+  auto kern = fle_pred_w_kernel<W, KIND>;
+  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  int grid = grid_for_tiles(reinterpret_cast<const void*>(kern), tiles);
+  if (grid <= 0) return IPS_ERR_HIP;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, s, enc, n_rows, args, bitmap32);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+template <int W>
+static ips_status launch_pred_w(const uint64_t* enc, int64_t n_rows, const PredArgs& args,
+                                uint32_t* bitmap32, hipStream_t s) {
+  if (args.join != 0) return launch_pred_wk<W, kPredPair>(enc, n_rows, args, bitmap32, s);
+  if (args.op == 5) return launch_pred_wk<W, kPredInList>(enc, n_rows, args, bitmap32, s);
+  return launch_pred_wk<W, kPredSingle>(enc, n_rows, args, bitmap32, s);
+}
+
+ips_status IPS_CAT(launch_fle_pred_part_, IPS_PART)(int w, const uint64_t* enc, int64_t n_rows,
+                                                    const PredArgs& args, uint32_t* bitmap32,
+                                                    hipStream_t s) {
+#define IPS_CASE(N) \
+  case IPS_WLO + N: return launch_pred_w<IPS_WLO + N>(enc, n_rows, args, bitmap32, s);
+  switch (w) {
+    IPS_CASE(0) IPS_CASE(1) IPS_CASE(2) IPS_CASE(3) IPS_CASE(4) IPS_CASE(5) IPS_CASE(6) IPS_CASE(7)
+  }
+#undef IPS_CASE
+  set_error("bit width %d outside part starting at %d", w, IPS_WLO);
+  return IPS_ERR_INVALID_ARG;
+}
+
 }  // namespace ips

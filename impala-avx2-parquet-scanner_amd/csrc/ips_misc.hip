@@ -8,58 +8,6 @@
 namespace ips {
 
 // =============================================================================================
-// FleDecoder::Eq/Lt/Le/Gt/Ge/In on the encoded planes (fle-encoding.h:7962-8313), bitmap only.
-// Nothing is decoded: per 64 rows the wave reads w words and writes one.
-// =============================================================================================
-__global__ __launch_bounds__(kThreads) void fle_pred_kernel(const uint64_t* __restrict__ enc,
-                                                            int64_t n_rows, int w, PredArgs args,
-                                                            uint32_t* __restrict__ bitmap32) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
-  const int lane = lane_id();
-  const int wave = wave_id();
-  uint32_t* lds32 = lds_dyn + wave * (plane_tile_bytes(w) / 4);
-
-  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
-  const int64_t total_words = ((n_rows + 63) / 64) * w;
-  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
-  const int64_t bm_dwords = bitmap_dwords(n_rows);
-  int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-
-  u32x4 r[8];
-  if (tile < tiles) tile_load<8>(enc, tile, w, total_words, lane, r);
-  while (tile < tiles) {
-    tile_to_lds<8>(lds32, w, lane, r);
-    const int64_t next = tile + stride;
-    if (next < tiles) tile_load<8>(enc, next, w, total_words, lane, r);
-    wave_lds_fence();
-    uint32_t bm = finish_bitmap_dword(pred_from_lds(lds32, w, lane, args), tile, lane, n_rows);
-    const int64_t d = tile * 64 + lane;
-    if (d < bm_dwords) {
-      if (args.combine == 1) bm &= bitmap32[d];
-      else if (args.combine == 2) bm |= bitmap32[d];
-      bitmap32[d] = bm;
-    }
-    wave_lds_fence();
-    tile = next;
-  }
-}
-
-ips_status launch_fle_pred(int w, const uint64_t* enc, int64_t n_rows, const PredArgs& args,
-                           uint32_t* bitmap32, hipStream_t s) {
-  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
-  // LDS (4 * 256*(w|1) bytes per block) and VGPRs allow >= 4 blocks per CU for every w
-  int64_t want = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-  int64_t cap = (int64_t)device_cus() * 4 * grid_mult();
-  int grid = (int)(want < cap ? want : cap);
-  if (grid <= 0) return IPS_ERR_HIP;
-  size_t lds = (size_t)kWavesPerBlock * plane_tile_bytes(w);
-  hipLaunchKernelGGL(fle_pred_kernel, dim3(grid), dim3(kThreads), lds, s, enc, n_rows, w, args,
-                     bitmap32);
-  IPS_HIP_TRY(hipGetLastError());
-  return IPS_OK;
-}
-
-// =============================================================================================
 // PLAIN fixed-width pages: ParquetPlainEncoder::Eq/Lt/Le/Gt/Ge (parquet-common.h:197-250, int8
 // :335-383, int16 :400-449).  bit = x OP literal (SQL order; the REFERENCE order is obtained by
 // the caller swapping LT<->GT, LE<->GE).  Lane loads 16 bytes = RPL rows; the RPL ballots are

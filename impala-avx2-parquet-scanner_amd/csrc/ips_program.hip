@@ -356,15 +356,13 @@ ips_status launch_program(const Program& prog, int64_t n_rows, uint32_t* bitmap3
 using namespace ips;
 
 // ---------------------------------------------------------------------------------------------
-// Conjunct-chain strategy.  The common shape of a conjunct list -- a left-deep chain of AND/OR
-// whose operands are single leaves or two leaves on one column (BETWEEN = And(Ge, Le),
-// simple-predicates.h:145-153, hdfs-parquet-scanner.cc:1857-1862) -- needs no bitmap stack: the
-// first operand is written to the output bitmap and every further operand is AND-ed / OR-ed into
-// it by the stand-alone predicate kernels (one pass per column, both leaves of a BETWEEN in the
-// same pass).  Those kernels run at 55-70 % of the HBM roofline, the general program kernel at
-// ~20 %, so the extra read-modify-write of the bitmap (2 bits per row and operand) is cheap.
-// Anything else (an OR of ANDs, operands that must be kept while another subtree is evaluated)
-// goes to program_kernel.
+// Per-operand strategy (the default).  Every operand -- a single leaf, or two leaves on one
+// column (BETWEEN = And(Ge, Le), simple-predicates.h:145-153, hdfs-parquet-scanner.cc:1857-1862)
+// evaluated in the same pass -- is one launch of a stand-alone predicate kernel that writes, ANDs
+// or ORs its result into a bitmap.  Those kernels run at 70-78 % of the HBM roofline (the
+// measured read ceiling of the part), the single-launch program_kernel at ~20 %, so the extra
+// read-modify-write of the bitmap (2 bits per row and operand) is cheap.  program_kernel stays
+// as the one-launch alternative (IPS_PROGRAM_NO_CHAIN=1).
 // ---------------------------------------------------------------------------------------------
 namespace {
 
@@ -403,47 +401,72 @@ ips_status emit_item(const ChainItem& it, int combine, const ips_column* cols, i
                            combine, it.b ? it.join : 0, it.b ? it.b->op : 0, it.b ? lit2 : nullptr);
 }
 
-// returns IPS_OK and *handled = true when the program was a chain and has been launched
+// Plans the whole tree on a stack of bitmaps.  Operands are folded into an existing bitmap
+// whenever one side of an AND / OR already is one (both commute); two leaf operands open a new
+// bitmap; two bitmaps are merged by ips_bitmap_and / or's kernel.  The bitmap the root ends up in
+// is mapped onto d_bitmap, the others (a left-deep conjunct chain has none) live in one
+// stream-ordered temporary allocation.
+// returns IPS_OK and *handled = true when the plan has been launched
 ips_status try_chain(const ips_node* nodes, int n_nodes, const ips_column* cols, int64_t n_rows,
                      uint64_t* d_bitmap, hipStream_t s, bool* handled) {
   *handled = false;
-  // pass 1: parse without launching anything
-  struct Launch { ChainItem item; int combine; };
-  Launch plan[IPS_PROGRAM_MAX_NODES];
-  int n_plan = 0;
-  ChainItem stack[IPS_PROGRAM_MAX_NODES];
+  struct Item { int slot; const ips_node* a; const ips_node* b; int join; };  // slot < 0: leaf / pair
+  struct Step { int kind; Item item; int combine; int dst; int src; };         // 0 pred, 1 merge
+  Step plan[2 * IPS_PROGRAM_MAX_NODES];
+  int n_plan = 0, n_slots = 0;
+  Item stack[IPS_PROGRAM_MAX_NODES];
   int sp = 0;
-  bool have_acc = false;
   for (int i = 0; i < n_nodes; ++i) {
     const ips_node& nd = nodes[i];
     if (nd.kind == IPS_NODE_LEAF) {
-      stack[sp++] = ChainItem{false, &nd, nullptr, 0};
+      stack[sp++] = Item{-1, &nd, nullptr, 0};
       continue;
     }
     const int op = nd.kind == IPS_NODE_AND ? 1 : 2;
-    ChainItem b = stack[--sp];
-    ChainItem a = stack[--sp];
-    if (!a.acc && !b.acc && !a.b && !b.b && a.a->column == b.a->column &&
-        a.a->op != IPS_OP_IN && b.a->op != IPS_OP_IN) {
-      stack[sp++] = ChainItem{false, a.a, b.a, op};  // two leaves on one column: one pass
-    } else if (a.acc != b.acc) {  // AND / OR commute: fold the operand into the accumulator
-      plan[n_plan++] = Launch{a.acc ? b : a, op};
-      stack[sp++] = ChainItem{true, nullptr, nullptr, 0};
-    } else if (!a.acc && !b.acc && !have_acc) {
-      plan[n_plan++] = Launch{a, 0};
-      plan[n_plan++] = Launch{b, op};
-      have_acc = true;
-      stack[sp++] = ChainItem{true, nullptr, nullptr, 0};
+    Item y = stack[--sp];
+    Item x = stack[--sp];
+    if (x.slot < 0 && y.slot < 0 && !x.b && !y.b && x.a->column == y.a->column &&
+        x.a->op != IPS_OP_IN && y.a->op != IPS_OP_IN) {
+      stack[sp++] = Item{-1, x.a, y.a, op};  // two leaves on one column: one pass
+    } else if (x.slot >= 0 && y.slot >= 0) {
+      plan[n_plan++] = Step{1, Item{}, op, x.slot, y.slot};
+      stack[sp++] = x;
+    } else if (x.slot >= 0 || y.slot >= 0) {
+      const Item& bm = x.slot >= 0 ? x : y;
+      plan[n_plan++] = Step{0, x.slot >= 0 ? y : x, op, bm.slot, -1};
+      stack[sp++] = bm;
     } else {
-      return IPS_OK;  // needs a second live bitmap: not a chain
+      const int slot = n_slots++;
+      plan[n_plan++] = Step{0, x, 0, slot, -1};
+      plan[n_plan++] = Step{0, y, op, slot, -1};
+      stack[sp++] = Item{slot, nullptr, nullptr, 0};
     }
   }
   if (sp != 1) return IPS_OK;
-  if (!stack[0].acc) plan[n_plan++] = Launch{stack[0], 0};
-  for (int i = 0; i < n_plan; ++i) {
-    ips_status st = emit_item(plan[i].item, plan[i].combine, cols, n_rows, d_bitmap, s);
-    if (st != IPS_OK) return st;
+  if (stack[0].slot < 0) {
+    plan[n_plan++] = Step{0, stack[0], 0, n_slots, -1};
+    stack[0].slot = n_slots++;
   }
+  const int root = stack[0].slot;
+  const size_t bitmap_bytes = (size_t)((n_rows + 63) / 64) * 8;
+  const size_t slot_bytes = (bitmap_bytes + 255) & ~(size_t)255;
+  uint8_t* temp = nullptr;
+  if (n_slots > 1) IPS_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&temp), slot_bytes * (size_t)(n_slots - 1), s));
+  auto slot_ptr = [&](int slot) -> uint64_t* {
+    if (slot == root) return d_bitmap;
+    return reinterpret_cast<uint64_t*>(temp + slot_bytes * (size_t)(slot < root ? slot : slot - 1));
+  };
+  ips_status st = IPS_OK;
+  for (int i = 0; i < n_plan && st == IPS_OK; ++i) {
+    const Step& p = plan[i];
+    if (p.kind == 0) st = emit_item(ChainItem{false, p.item.a, p.item.b, p.item.join}, p.combine, cols, n_rows, slot_ptr(p.dst), s);
+    else st = launch_bitmap_binop(p.combine == 1 ? 0 : 1, slot_ptr(p.dst), slot_ptr(p.src), (n_rows + 63) / 64, s);
+  }
+  if (temp) {
+    hipError_t e = hipFreeAsync(temp, s);
+    if (st == IPS_OK && e != hipSuccess) st = hip_fail(e, "hipFreeAsync");
+  }
+  if (st != IPS_OK) return st;
   *handled = true;
   return IPS_OK;
 }

@@ -218,11 +218,21 @@ def test_fused_program(capi, O, strategy, monkeypatch):
         got = bits_of(words(capi.eval_program(nodes, cols, n)), n)
         exp = (((p32 > 100) | (p64 <= 0)) & np.isin(c1, [1, 9, 15])) | (pf64 < -3.5)
         assert np.array_equal(got, exp), n
-        # (A and B) or (C and D): needs two live bitmaps -> always the general kernel
+        # (A and B) or (C and D): two live bitmaps
         nodes = [L(0, O.OP_LT, 2000), PL(3, O.OP_GE, np.int32(0), O.T_INT32), AND(),
                  L(2, O.OP_GE, 1 << 19), PL(4, O.OP_LT, np.int64(5), O.T_INT64), AND(), OR()]
         got = bits_of(words(capi.eval_program(nodes, cols, n)), n)
         exp = ((c0 < 2000) & (p32 >= 0)) | ((c2 >= (1 << 19)) & (p64 < 5))
+        assert np.array_equal(got, exp), n
+        # leaf OP (subtree): the root ends up in the later bitmap; three bitmaps live at once
+        nodes = [L(1, O.OP_GT, 2),
+                 L(0, O.OP_LT, 900), PL(3, O.OP_LT, np.int32(-500), O.T_INT32), OR(),
+                 L(2, O.OP_GE, 1 << 20), PL(4, O.OP_GT, np.int64(0), O.T_INT64), AND(),
+                 PL(5, O.OP_GT, np.float64(12.0), O.T_DOUBLE), L(0, O.OP_GE, 4000), OR(),
+                 OR(), AND(), AND()]
+        got = bits_of(words(capi.eval_program(nodes, cols, n)), n)
+        exp = (c1 > 2) & (((c0 < 900) | (p32 < -500)) &
+                          (((c2 >= (1 << 20)) & (p64 > 0)) | ((pf64 > 12.0) | (c0 >= 4000))))
         assert np.array_equal(got, exp), n
         # BETWEEN on a PLAIN column + OR-chain
         nodes = [PL(5, O.OP_GE, np.float64(-1.0), O.T_DOUBLE), PL(5, O.OP_LE, np.float64(2.5), O.T_DOUBLE),

@@ -160,6 +160,23 @@ def main():
     tmin, tmed = timeit(leafwise)
     report("configs[4] same conjunction, leaf-by-leaf launches + bitmap ANDs", nq, byts, tmin, tmed,
            torch.equal(tmp[0], bm))
+    # an OR of two conjunctions over the same columns: two bitmaps live at once
+    OR = capi.or_node
+    nodes2 = [L(0, capi.OP_GE, 365), L(0, capi.OP_LT, 730), AND(), L(1, capi.OP_LT, 3), AND(),
+              L(2, capi.OP_GE, 40), L(1, capi.OP_GE, 9), AND(), OR()]
+    exp2 = int((((cols_codes[0] >= 365) & (cols_codes[0] < 730) & (cols_codes[1] < 3))
+                | ((cols_codes[2] >= 40) & (cols_codes[1] >= 9))).sum().item())
+    byts2 = (12 + 4 + 6 + 4) * 8 * Wq + 8 * Wq
+    for label, env in (("per-operand launches + one bitmap OR", None), ("one-launch program kernel", "1")):
+        if env:
+            os.environ["IPS_PROGRAM_NO_CHAIN"] = env
+        else:
+            os.environ.pop("IPS_PROGRAM_NO_CHAIN", None)
+        f2 = lambda: capi.eval_program(nodes2, cols, nq, bitmap=bm)
+        tmin, tmed = timeit(f2)
+        report(f"configs[4] (A and B and C) or (D and E), {label}", nq, byts2, tmin, tmed,
+               capi.bitmap_count(bm, nq) == exp2)
+    os.environ.pop("IPS_PROGRAM_NO_CHAIN", None)
     json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
                                      "configs_bench.json"), "w"), indent=1)
 
