@@ -51,57 +51,75 @@ __device__ __forceinline__ T slot_value(S raw) {
   }
 }
 
+// A wave takes 8 consecutive chunks (8 KiB of the page) per iteration: the eight 16-byte loads of a
+// lane are issued back to back, and the 8*RPL bitmap words they produce leave as one contiguous
+// store (128 or 256 bytes) instead of eight small ones.
+constexpr int kPlainChunksPerTile = 8;
+
 template <typename T, typename S>
 __global__ __launch_bounds__(kThreads) void plain_pred_kernel(const S* __restrict__ page,
                                                               int64_t n_rows, int op,
                                                               PlainLit<T> lit,
                                                               uint64_t* __restrict__ bitmap) {
   constexpr int RPL = 16 / sizeof(S);  // rows per lane per load: 4 or 2
+  constexpr int U = kPlainChunksPerTile;
   const int lane = lane_id();
   const int64_t wave_g = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
   const int64_t waves = (int64_t)gridDim.x * kWavesPerBlock;
   const int64_t rows_per_chunk = 64 * RPL;
-  const int64_t chunks = (n_rows + rows_per_chunk - 1) / rows_per_chunk;
+  const int64_t rows_per_tile = rows_per_chunk * U;
+  const int64_t tiles = (n_rows + rows_per_tile - 1) / rows_per_tile;
   const int64_t n_words = (n_rows + 63) / 64;
 
-  for (int64_t chunk = wave_g; chunk < chunks; chunk += waves) {
-    const int64_t row0 = chunk * rows_per_chunk + (int64_t)lane * RPL;
-    S raw[RPL];
-    if (row0 + RPL <= n_rows) {
-      u32x4 t = *reinterpret_cast<const u32x4*>(page + row0);
-      __builtin_memcpy(raw, &t, 16);
+  for (int64_t tile = wave_g; tile < tiles; tile += waves) {
+    const int64_t tile_row0 = tile * rows_per_tile;
+    S raw[U][RPL];
+    if (tile_row0 + rows_per_tile <= n_rows) {  // wave-uniform: full tile
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        u32x4 t = *reinterpret_cast<const u32x4*>(page + tile_row0 + u * rows_per_chunk + lane * RPL);
+        __builtin_memcpy(raw[u], &t, 16);
+      }
     } else {
 #pragma unroll
-      for (int e = 0; e < RPL; ++e) raw[e] = row0 + e < n_rows ? page[row0 + e] : (S)0;
-    }
-    uint64_t m[RPL];
+      for (int u = 0; u < U; ++u) {
+        const int64_t row0 = tile_row0 + u * rows_per_chunk + (int64_t)lane * RPL;
 #pragma unroll
-    for (int e = 0; e < RPL; ++e) {
-      const T x = slot_value<T, S>(raw[e]);
-      bool b = plain_cmp<T>(x, op, lit);
-      if (lit.join != 0) {
-        PlainLit<T> l2;
-        l2.v[0] = lit.v2;
-        l2.n = 1;
-        const bool b2 = plain_cmp<T>(x, lit.op2, l2);
-        b = lit.join == 1 ? (b && b2) : (b || b2);
+        for (int e = 0; e < RPL; ++e) raw[u][e] = row0 + e < n_rows ? page[row0 + e] : (S)0;
       }
-      b = b && (row0 + e < n_rows);
-      m[e] = __builtin_amdgcn_ballot_w64(b);  // bit l <-> row RPL*l + e of the chunk
     }
-    // row 64*j + t of the chunk sits in ballot (t % RPL) at bit (64*j + t) / RPL
-    uint64_t sel;
-    if (RPL == 4) sel = (lane & 2) ? ((lane & 1) ? m[3] : m[2]) : ((lane & 1) ? m[1] : m[0]);
-    else sel = (lane & 1) ? m[1] : m[0];
     uint64_t mine = 0;
 #pragma unroll
-    for (int j = 0; j < RPL; ++j) {
-      int src = (64 * j + lane) / RPL;
-      uint64_t word = __builtin_amdgcn_ballot_w64(((sel >> src) & 1ull) != 0ull);
-      if (lane == j) mine = word;
+    for (int u = 0; u < U; ++u) {
+      const int64_t row0 = tile_row0 + u * rows_per_chunk + (int64_t)lane * RPL;
+      uint64_t m[RPL];
+#pragma unroll
+      for (int e = 0; e < RPL; ++e) {
+        const T x = slot_value<T, S>(raw[u][e]);
+        bool b = plain_cmp<T>(x, op, lit);
+        if (lit.join != 0) {
+          PlainLit<T> l2;
+          l2.v[0] = lit.v2;
+          l2.n = 1;
+          const bool b2 = plain_cmp<T>(x, lit.op2, l2);
+          b = lit.join == 1 ? (b && b2) : (b || b2);
+        }
+        b = b && (row0 + e < n_rows);
+        m[e] = __builtin_amdgcn_ballot_w64(b);  // bit l <-> row RPL*l + e of the chunk
+      }
+      // row 64*j + t of the chunk sits in ballot (t % RPL) at bit (64*j + t) / RPL
+      uint64_t sel;
+      if (RPL == 4) sel = (lane & 2) ? ((lane & 1) ? m[3] : m[2]) : ((lane & 1) ? m[1] : m[0]);
+      else sel = (lane & 1) ? m[1] : m[0];
+#pragma unroll
+      for (int j = 0; j < RPL; ++j) {
+        int src = (64 * j + lane) / RPL;
+        uint64_t word = __builtin_amdgcn_ballot_w64(((sel >> src) & 1ull) != 0ull);
+        if (lane == u * RPL + j) mine = word;
+      }
     }
-    const int64_t wi = chunk * RPL + lane;
-    if (lane < RPL && wi < n_words) {
+    const int64_t wi = tile * (U * RPL) + lane;
+    if (lane < U * RPL && wi < n_words) {
       if (lit.combine == 1) mine &= bitmap[wi];
       else if (lit.combine == 2) mine |= bitmap[wi];
       bitmap[wi] = mine;
@@ -121,9 +139,9 @@ static ips_status launch_plain_t(const void* page, int64_t n_rows, int op, const
   lit.v2 = literal2 ? *reinterpret_cast<const T*>(literal2) : T();
   for (int i = 0; i < 16; ++i) lit.v[i] = i < n_literals ? reinterpret_cast<const T*>(literals)[i] : T();
   constexpr int RPL = 16 / sizeof(S);
-  int64_t chunks = (n_rows + 64 * RPL - 1) / (64 * RPL);
-  int64_t want = (chunks + kWavesPerBlock - 1) / kWavesPerBlock;
-  int64_t cap = (int64_t)device_cus() * 8;
+  int64_t tiles = (n_rows + 64 * RPL * kPlainChunksPerTile - 1) / (64 * RPL * kPlainChunksPerTile);
+  int64_t want = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  int64_t cap = (int64_t)device_cus() * 8 * grid_mult();
   int grid = (int)(want < cap ? want : cap);
   if (grid <= 0) return IPS_ERR_HIP;
   hipLaunchKernelGGL((plain_pred_kernel<T, S>), dim3(grid), dim3(kThreads), 0, s,
