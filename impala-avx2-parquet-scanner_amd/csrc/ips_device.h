@@ -61,7 +61,20 @@ __device__ __forceinline__ uint32_t bit_mask(uint32_t c, int k) {
 // A full sub-tile is 32*W words = 16*W chunks of 16 bytes; lane l takes chunks l, l+64, ...
 // MAXLOADS = ceil(16*W/64).  'total_words' bounds the encoded buffer: nothing beyond
 // ceil(n/64)*W words is ever read (the reference's unpackers over-read 32 bytes, quirk Q5).
-template <int MAXLOADS>
+// 16-byte load of data that is read exactly once (column pages): the nt hint keeps the stream from
+// displacing the kernel's own dirty output lines in L2, so those leave for HBM in larger bursts.
+// Measured on the headline scan: 252 -> 224 us, predicate only: 204 -> 180 us (2^28 rows, w=32).
+// Kernels whose output is as large as their input (decode) are better off without it (+4 %).
+template <bool NT = true>
+__device__ __forceinline__ u32x4 stream_load(const u32x4* p) {
+#ifdef IPS_NO_NT_LOADS
+  return *p;
+#else
+  return NT ? __builtin_nontemporal_load(p) : *p;
+#endif
+}
+
+template <int MAXLOADS, bool NT = true>
 __device__ __forceinline__ void tile_load(const uint64_t* __restrict__ enc, int64_t tile, int w,
                                           int64_t total_words, int lane, u32x4 (&r)[MAXLOADS]) {
   const int64_t w0 = tile * (int64_t)(kBlocksPerTile * w);
@@ -71,7 +84,7 @@ __device__ __forceinline__ void tile_load(const uint64_t* __restrict__ enc, int6
 #pragma unroll
     for (int i = 0; i < MAXLOADS; ++i) {
       int c = i * kWave + lane;
-      if (c < chunks) r[i] = *reinterpret_cast<const u32x4*>(base + 2 * c);
+      if (c < chunks) r[i] = stream_load<NT>(reinterpret_cast<const u32x4*>(base + 2 * c));
     }
   } else {
     const int64_t left = total_words - w0;  // words available in this (last) tile

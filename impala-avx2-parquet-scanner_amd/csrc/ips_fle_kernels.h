@@ -211,11 +211,11 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_decode_ker
   int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
 
   u32x4 r[L];
-  if (tile < tiles) tile_load<L>(enc, tile, W, total_words, lane, r);
+  if (tile < tiles) tile_load<L, false>(enc, tile, W, total_words, lane, r);
   while (tile < tiles) {
     tile_to_lds<L>(lds32, W, lane, r);
     const int64_t next = tile + stride;
-    if (next < tiles) tile_load<L>(enc, next, W, total_words, lane, r);
+    if (next < tiles) tile_load<L, false>(enc, next, W, total_words, lane, r);
     wave_lds_fence();
 
     uint32_t p[W];

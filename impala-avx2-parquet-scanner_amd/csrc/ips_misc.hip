@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kThreads) void plain_pred_kernel(const S* __restric
     if (tile_row0 + rows_per_tile <= n_rows) {  // wave-uniform: full tile
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        u32x4 t = *reinterpret_cast<const u32x4*>(page + tile_row0 + u * rows_per_chunk + lane * RPL);
+        u32x4 t = stream_load(reinterpret_cast<const u32x4*>(page + tile_row0 + u * rows_per_chunk + lane * RPL));
         __builtin_memcpy(raw[u], &t, 16);
       }
     } else {

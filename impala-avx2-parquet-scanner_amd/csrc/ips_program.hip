@@ -66,7 +66,7 @@ __device__ __forceinline__ void job_load(const void* data, int kind, int w, int6
       const int64_t valid = n_rows - (row_base + rho);
       u32x4 t = {0u, 0u, 0u, 0u};
       if (valid >= 4) {
-        t = *reinterpret_cast<const u32x4*>(page + row_base + rho);
+        t = stream_load(reinterpret_cast<const u32x4*>(page + row_base + rho));
       } else {
         if (valid > 0) t.x = page[row_base + rho];
         if (valid > 1) t.y = page[row_base + rho + 1];
@@ -83,7 +83,7 @@ __device__ __forceinline__ void job_load(const void* data, int kind, int w, int6
       const int64_t valid = n_rows - (row_base + rr);
       u32x4 t = {0u, 0u, 0u, 0u};
       if (valid >= 2) {
-        t = *reinterpret_cast<const u32x4*>(page + row_base + rr);
+        t = stream_load(reinterpret_cast<const u32x4*>(page + row_base + rr));
       } else if (valid > 0) {
         u32x2 q = *reinterpret_cast<const u32x2*>(page + row_base + rr);
         t.x = q.x; t.y = q.y;
