@@ -238,6 +238,38 @@ __device__ __forceinline__ uint32_t pred_from_regs(const uint32_t (&p)[W], const
   return cmp_select(s, a.op);
 }
 
+// IN on planes in registers (W <= 16: every dictionary code width): one bit-select op per plane
+// and constant, four constants per round so the scalar loads of the list are batched.
+template <int W, typename ConstsPtrT>
+__device__ __forceinline__ uint32_t pred_in_from_regs(const uint32_t (&p)[W], ConstsPtrT consts,
+                                                      int n_consts) {
+  uint32_t any = 0u;
+  int j = 0;
+#pragma unroll 1
+  for (; j + 4 <= n_consts; j += 4) {
+    const uint32_t c0 = (uint32_t)consts[j], c1 = (uint32_t)consts[j + 1];
+    const uint32_t c2 = (uint32_t)consts[j + 2], c3 = (uint32_t)consts[j + 3];
+    uint32_t e0 = ~0u, e1 = ~0u, e2 = ~0u, e3 = ~0u;
+#pragma unroll
+    for (int k = W - 1; k >= 0; --k) {
+      e0 &= ~(p[k] ^ bit_mask(c0, k));
+      e1 &= ~(p[k] ^ bit_mask(c1, k));
+      e2 &= ~(p[k] ^ bit_mask(c2, k));
+      e3 &= ~(p[k] ^ bit_mask(c3, k));
+    }
+    any |= (e0 | e1) | (e2 | e3);
+  }
+#pragma unroll 1
+  for (; j < n_consts; ++j) {
+    const uint32_t c = (uint32_t)consts[j];
+    uint32_t eq = ~0u;
+#pragma unroll
+    for (int k = W - 1; k >= 0; --k) eq &= ~(p[k] ^ bit_mask(c, k));
+    any |= eq;
+  }
+  return any;
+}
+
 // Bitmap dword of this lane: bit j <-> row 32q+j of the block; rows >= n_rows are cleared.
 __device__ __forceinline__ uint32_t finish_bitmap_dword(uint32_t sel_msb_first, int64_t tile,
                                                         int lane, int64_t n_rows) {

@@ -18,6 +18,16 @@ struct GatherT { using type = uint32_t; };
 template <>
 struct GatherT<8> { using type = uint64_t; };
 
+// A dictionary that fits 4 KiB (every code of the width addressable: 2^W entries of G bytes) is
+// copied into LDS once per workgroup and the gather reads it there: a dependent global load per
+// selected value is what bounded the narrow dictionary scans (w=8 IN scan + gather 107 -> 87 us).
+// At 16 KiB (w=12) the per-workgroup copy and the lost occupancy cost more than they save.
+template <int W, int G>
+struct DictLds {
+  static constexpr bool kUse = G != 0 && W <= 12 && ((1 << (W <= 12 ? W : 0)) * G) <= 4096;
+  static constexpr int kEntries = kUse ? (1 << (W <= 12 ? W : 0)) : 1;
+};
+
 // ---------------------------------------------------------------------------------------------
 // Fused scan: predicate (or given bitmap) -> bitmap, selected rows decoded and written per batch.
 // Replaces EvalSimplePredicates + bitmap->skip-list + ReadValue(skip) of one column
@@ -32,10 +42,20 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kerne
     int32_t* __restrict__ bad_index) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kRowTileBytes / 4];
   using GT = typename GatherT<G>::type;
+  __shared__ GT dict_lds[DictLds<W, G>::kEntries];
   constexpr int L = (16 * W + kWave - 1) / kWave;
   const int lane = lane_id();
   const int wave = wave_id();
   uint32_t* lds32 = lds_all + wave * (kRowTileBytes / 4);
+  if constexpr (DictLds<W, G>::kUse) {
+    for (uint32_t i = threadIdx.x; i < dict_entries && i < (uint32_t)DictLds<W, G>::kEntries; i += kThreads)
+      dict_lds[i] = dict[i];
+    __syncthreads();
+  }
+  auto lookup = [&](uint32_t code) -> GT {
+    if constexpr (DictLds<W, G>::kUse) return dict_lds[code];
+    else return dict[code];
+  };
 
   const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   const int64_t total_words = ((n_rows + 63) / 64) * W;
@@ -53,12 +73,16 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kerne
 
     const int64_t d = tile * 64 + lane;
     uint32_t bm;
-    if (MODE == kScanInList) {  // IN: K passes over the planes in LDS, before they enter VGPRs
+    if (MODE == kScanInList && W > 16) {  // wide IN: K passes over the planes in LDS, before they enter VGPRs
       bm = finish_bitmap_dword(pred_from_lds(lds32, W, lane, args), tile, lane, n_rows);
       if (d < bm_dwords) bitmap32[d] = bm;
     }
     uint32_t p[W];
     planes_from_lds<W>(lds32, lane, p);
+    if (MODE == kScanInList && W <= 16) {
+      bm = finish_bitmap_dword(pred_in_from_regs<W>(p, args.consts, args.n_consts), tile, lane, n_rows);
+      if (d < bm_dwords) bitmap32[d] = bm;
+    }
     if (MODE == kScanPredicate) {
       bm = finish_bitmap_dword(pred_from_regs<W>(p, args), tile, lane, n_rows);
       if (d < bm_dwords) bitmap32[d] = bm;
@@ -104,7 +128,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kerne
               if (G == 0) {
                 dst[P] = (GT)x[e];
               } else if (x[e] < dict_entries) {
-                dst[P] = dict[x[e]];
+                dst[P] = lookup(x[e]);
               } else {
                 bad = 1;
               }
@@ -122,7 +146,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kerne
           int bad = 0;
           for (uint32_t e = lane; e < count; e += kWave) {
             uint32_t code = lds32[compact_dw(e)];
-            if (code < dict_entries) dst[e] = dict[code]; else bad = 1;
+            if (code < dict_entries) dst[e] = lookup(code); else bad = 1;
           }
           if (bad && bad_index) *bad_index = 1;
         }
@@ -174,6 +198,10 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_w_ker
       uint32_t r1, r2;
       pred_pair_from_lds(lds32, W, lane, args.op, args.consts[0], args.op2, args.const2, &r1, &r2);
       sel = args.join == 1 ? (r1 & r2) : (r1 | r2);
+    } else if (W <= 16) {
+      uint32_t p[W];
+      planes_from_lds<W>(lds32, lane, p);
+      sel = pred_in_from_regs<W>(p, args.consts, args.n_consts);
     } else {
       sel = pred_in_from_lds(lds32, W, lane, args.consts, args.n_consts);
     }
@@ -200,10 +228,21 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_decode_ker
     const typename GatherT<G>::type* __restrict__ dict, uint32_t dict_entries,
     int32_t* __restrict__ bad_index) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kRowTileBytes / 4];
+  using GT = typename GatherT<G>::type;
+  __shared__ GT dict_lds[DictLds<W, G>::kEntries];
   constexpr int L = (16 * W + kWave - 1) / kWave;
   const int lane = lane_id();
   const int wave = wave_id();
   uint32_t* lds32 = lds_all + wave * (kRowTileBytes / 4);
+  if constexpr (DictLds<W, G>::kUse) {
+    for (uint32_t i = threadIdx.x; i < dict_entries && i < (uint32_t)DictLds<W, G>::kEntries; i += kThreads)
+      dict_lds[i] = dict[i];
+    __syncthreads();
+  }
+  auto lookup = [&](uint32_t code) -> GT {
+    if constexpr (DictLds<W, G>::kUse) return dict_lds[code];
+    else return dict[code];
+  };
 
   const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   const int64_t total_words = ((n_rows + 63) / 64) * W;
@@ -235,7 +274,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_decode_ker
         int rho = i * kWave + lane;
         if (row_base + rho < n_rows) {
           uint32_t code = lds32[row_tile_dw(rho)];
-          if (code < dict_entries) dst[row_base + rho] = dict[code]; else bad = 1;
+          if (code < dict_entries) dst[row_base + rho] = lookup(code); else bad = 1;
         }
       }
       if (bad && bad_index) *bad_index = 1;

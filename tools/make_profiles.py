@@ -91,3 +91,20 @@ with open(os.path.join(dst, f"{tag}_sq_counters.md"), "w") as f:
         v = statistics.mean(acc[k])
         f.write(f"| {k} | {v:.0f} | {v / tiles:.1f} |\n")
 print(json.dumps(traffic, indent=1))
+
+
+# 5. BASELINE configs[2..4] (tools/configs_bench.py writes gpurun_out/configs_bench.json)
+cfg = os.path.join(ROOT, "gpurun_out", "configs_bench.json")
+if os.path.exists(cfg):
+    rows = json.load(open(cfg))
+    with open(os.path.join(dst, f"{tag}_configs_bench.md"), "w") as f:
+        f.write(f"# {tag}: BASELINE.json configs[2..4] on one MI355X (tools/configs_bench.py)\n\n")
+        f.write("Kernel time = median of 10 launches (HIP events), inputs resident in HBM. `check` = result "
+                "equals an independent torch/numpy evaluation of the same predicate. `ips_eval_program` plans "
+                "the tree per operand (stand-alone predicate kernels writing / AND-ing / OR-ing into a bitmap, "
+                "both leaves of a BETWEEN in one pass) unless the row says otherwise.\n\n")
+        f.write("| config | rows | algorithmic MB | median us | GB/s | % of 8 TB/s | Grows/s | check |\n")
+        f.write("|---|---|---|---|---|---|---|---|\n")
+        for r in rows:
+            f.write(f"| {r['config']} | {r['rows']} | {r['algorithmic_bytes'] / 1e6:.0f} | {r['us_med']} | "
+                    f"{r['GBps_med']} | {r['GBps_med'] / 80:.1f} | {r['Grows_per_s_med']} | {r['check']} |\n")
