@@ -72,6 +72,25 @@ def test_pred_vs_oracle(capi, O, bw):
         assert np.array_equal(got, O.fle_pred(ref_enc, n, bw, O.OP_IN, lst)), (bw, n)
 
 
+@pytest.mark.parametrize("bw", [3, 8, 12, 16, 17, 32])
+def test_in_list_lengths(capi, O, bw):
+    """IN lists of every length class of the kernels' constant loops (rounds of four + remainder,
+    up to IPS_MAX_IN_LIST = 256), predicate-only and fused scan; duplicates allowed."""
+    rng = np.random.default_rng(900 + bw)
+    n = 6000
+    vals = rand_vals(rng, n, bw)
+    ref_enc = O.fle_encode(vals, bw)
+    enc = enc_to_dev(ref_enc)
+    for k in (1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 63, 255, 256):
+        lst = [int(x) for x in rng.choice(vals, k)]          # present values, maybe repeated
+        lst[k // 2] = int(rng.integers(0, 1 << bw))           # plus one that may be absent
+        ref = O.fle_pred(ref_enc, n, bw, O.OP_IN, lst)
+        assert np.array_equal(words(capi.fle_pred(enc, n, bw, O.OP_IN, lst)), ref), (bw, k)
+        bitmap, bvals, counts = capi.fle_scan(enc, n, bw, O.OP_IN, lst)
+        assert np.array_equal(words(bitmap), ref), (bw, k)
+        check_batches(bvals, counts, n, O.fle_select(ref_enc, n, bw, ref), capi)
+
+
 def check_batches(bvals, counts, n, expect_dense, capi):
     counts_h = counts.cpu().numpy()
     b_h = bvals.cpu().numpy().view(np.uint32)
