@@ -293,6 +293,14 @@ def main():
                               "us_per_launch_hipgraph_replay": graph_us and round(graph_us, 2)},
                   "device": capi.device_info()[0]},
     }
+    if gather:
+        # the exchange next to the scan: what the stripes alone sustain, and what one step moves
+        out["extra"]["exchange"] = {
+            "scan_only_rows_per_s": round(total_rows / (kern_avg_ms * 1e-3), 1),
+            "bitmap_bytes_sent_per_rank_per_step": words * 8,
+            "bitmap_bytes_received_per_rank_per_step": words * 8 * (world - 1),
+            "note": "value includes the all-gather (overlapped with the next step's scan); "
+                    "scan_only = total rows / rank 0's average scan-kernel time in the same run"}
     print(json.dumps(out))
     if gather:
         dist.destroy_process_group()

@@ -10,7 +10,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def test_bitops_on_host():
     with tempfile.TemporaryDirectory() as d:
         exe = os.path.join(d, "host_bitops_test")
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe,
+        # AddressSanitizer + UBSan: the GPU pool has no sanitizers, the shared arithmetic gets them here
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined",
+                               "-fno-sanitize-recover=undefined", "-o", exe,
                                os.path.join(HERE, "host_bitops_test.cpp")])
-        r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+        env.pop("LD_PRELOAD", None)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stdout + r.stderr
