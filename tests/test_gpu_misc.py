@@ -385,6 +385,9 @@ def test_dict_encode_on_gpu(capi, O, type_name):
             assert int(bad.item()) == 0
             assert np.array_equal(out.cpu().numpy().astype(O.NP_TYPES[t]), vals)
             dd.close()
+    if t == O.T_INT32:
+        page, bw, enc = capi.dict_encode(torch.zeros(16, dtype=torch.int32, device="cuda")[:0], t)
+        assert len(page) == 0 and bw == 0 and enc.numel() == 0      # empty chunk
     # the 40000-entry cap of the reference
     if t == O.T_INT32:
         big = torch.arange(0, 50000, dtype=torch.int32, device="cuda")
