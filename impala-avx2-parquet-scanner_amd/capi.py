@@ -212,11 +212,12 @@ def batches_compact(bvals, counts, n_rows, stream=None):
     return dense[:int(total.item())]
 
 
-def assemble_tuples(columns, counts, n_rows, tuple_size, stream=None):
+def assemble_tuples(columns, counts, n_rows, tuple_size, template=None, stream=None):
     """columns: list of (batch_values tensor, tuple_offset) for REQUIRED columns or
     (dense_values, tuple_offset, nonnull_flags, null_byte_offset, null_bit_mask) for OPTIONAL
-    ones, all selected by the bitmap behind 'counts'.  Returns a uint8 tensor
-    [n_tuples, tuple_size] of row-major tuples in row order (untouched bytes are zero)."""
+    ones, all selected by the bitmap behind 'counts'.  template: tuple_size bytes every tuple
+    starts from (None = zeros).  Returns a uint8 tensor [n_tuples, tuple_size] of row-major tuples
+    in row order."""
     dev = counts.device
     arr = (TupleColumn * len(columns))()
     n_opt = 0
@@ -236,8 +237,13 @@ def assemble_tuples(columns, counts, n_rows, tuple_size, stream=None):
                      dtype=torch.uint8, device=dev)
     total = torch.zeros(1, dtype=torch.int64, device=dev)
     cap = int(counts.to(torch.int64).sum().item())
-    tuples = torch.zeros(max(cap, 1) * tuple_size, dtype=torch.uint8, device=dev)
+    tuples = torch.full((max(cap, 1) * tuple_size + 16,), 0xA5, dtype=torch.uint8, device=dev)
+    tmpl = None
+    if template is not None:
+        tmpl = np.ascontiguousarray(template, dtype=np.uint8)
+        assert len(tmpl) == tuple_size
     _ck(lib().ips_assemble_tuples(arr, len(columns), _ptr(counts), C.c_int64(n_rows), tuple_size,
+                                  tmpl.ctypes.data_as(C.c_void_p) if tmpl is not None else None,
                                   _ptr(tuples), _ptr(total), _ptr(ws), _stream(stream)))
     n = int(total.item())
     return tuples[:n * tuple_size].view(n, tuple_size)

@@ -103,11 +103,12 @@ ips_status launch_batches_compact(const void* batch_values, const uint32_t* coun
                                   int64_t n_batches, int value_width, void* dense, int64_t* total,
                                   void* workspace, hipStream_t s);
 ips_status launch_assemble_tuples(const ips_tuple_column* cols, int n_cols, const uint32_t* counts,
-                                  int64_t n_batches, int tuple_size, void* tuples, int64_t* total,
-                                  void* workspace, hipStream_t s);
+                                  int64_t n_batches, int tuple_size, const void* h_template,
+                                  void* tuples, int64_t* total, void* workspace, hipStream_t s);
 ips_status launch_synth(uint64_t seed, int64_t n, uint32_t mask, uint32_t* out, hipStream_t s);
 size_t scan_workspace_bytes(int64_t items);
 size_t assemble_workspace_bytes(int64_t n_batches, int n_optional);
+size_t batches_workspace_bytes(int64_t n_batches);
 ips_status launch_bitmap_compress(const uint64_t* mask, const uint64_t* src, int64_t n_rows,
                                   uint64_t* out, int64_t* n_out, void* workspace, hipStream_t s);
 
@@ -353,7 +354,7 @@ ips_status ips_fle_select(const void* d_enc, int64_t n_rows, int bit_width,
                          d_batch_values, d_batch_counts, nullptr, 0, nullptr, S(stream));
 }
 
-size_t ips_batches_workspace_bytes(int64_t n_rows) { return scan_workspace_bytes(n_batches_of(n_rows)); }
+size_t ips_batches_workspace_bytes(int64_t n_rows) { return batches_workspace_bytes(n_batches_of(n_rows)); }
 
 ips_status ips_batches_compact(const void* d_batch_values, const uint32_t* d_batch_counts,
                                int64_t n_rows, int value_width, void* d_dense, int64_t* d_total,
@@ -368,8 +369,8 @@ ips_status ips_batches_compact(const void* d_batch_values, const uint32_t* d_bat
 
 ips_status ips_assemble_tuples(const ips_tuple_column* cols, int n_cols,
                                const uint32_t* d_batch_counts, int64_t n_rows, int tuple_size,
-                               void* d_tuples, int64_t* d_total, void* d_workspace,
-                               ips_stream stream) {
+                               const void* h_template_tuple, void* d_tuples, int64_t* d_total,
+                               void* d_workspace, ips_stream stream) {
   IPS_REQUIRE(cols && n_cols >= 1 && n_cols <= IPS_TUPLE_MAX_COLS, "ips_assemble_tuples: n_cols %d not in 1..%d", n_cols, IPS_TUPLE_MAX_COLS);
   IPS_REQUIRE(n_rows >= 0 && tuple_size > 0, "ips_assemble_tuples: bad n_rows / tuple_size");
   IPS_REQUIRE(d_total && d_workspace, "ips_assemble_tuples: NULL total/workspace");
@@ -388,7 +389,7 @@ ips_status ips_assemble_tuples(const ips_tuple_column* cols, int n_cols,
     }
   }
   return launch_assemble_tuples(cols, n_cols, d_batch_counts, n_batches_of(n_rows), tuple_size,
-                                d_tuples, d_total, d_workspace, S(stream));
+                                h_template_tuple, d_tuples, d_total, d_workspace, S(stream));
 }
 
 size_t ips_assemble_workspace_bytes(int64_t n_rows, int n_optional_cols) {

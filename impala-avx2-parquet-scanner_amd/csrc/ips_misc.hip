@@ -191,19 +191,38 @@ __global__ void bitmap_fill_kernel(uint64_t* __restrict__ a, int64_t n_rows, int
   }
 }
 
-__global__ void bitmap_count_kernel(const uint64_t* __restrict__ a, int64_t n_rows,
-                                    unsigned long long* __restrict__ count) {
+__global__ __launch_bounds__(256) void bitmap_count_kernel(const uint64_t* __restrict__ a,
+                                                           int64_t n_rows,
+                                                           unsigned long long* __restrict__ count) {
+  __shared__ unsigned long long part[4];
   const int64_t n_words = (n_rows + 63) / 64;
+  const int64_t n_pairs = n_words / 2;  // 16-byte loads; the last (maybe partial) words go scalar
   unsigned long long c = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words;
+  const ulonglong2* a2 = reinterpret_cast<const ulonglong2*>(a);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs;
        i += (int64_t)gridDim.x * blockDim.x) {
-    uint64_t w = a[i];
-    int64_t valid = n_rows - i * 64;
-    if (valid < 64) w &= (1ull << valid) - 1ull;
-    c += __builtin_popcountll(w);
+    if (2 * i + 2 < n_words) {  // both words are full
+      ulonglong2 w = a2[i];
+      c += __builtin_popcountll(w.x) + __builtin_popcountll(w.y);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 4) {  // the <= 3 trailing words, with the row mask
+    const int64_t first = n_pairs >= 1 ? 2 * (n_pairs - 1) : 0;
+    const int64_t i = first + threadIdx.x;
+    if (i < n_words && (i >= 2 * n_pairs || 2 * (i / 2) + 2 >= n_words)) {
+      uint64_t w = a[i];
+      int64_t valid = n_rows - i * 64;
+      if (valid < 64) w &= (1ull << valid) - 1ull;
+      c += __builtin_popcountll(w);
+    }
   }
   for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-  if (lane_id() == 0 && c) atomicAdd(count, c);
+  if (lane_id() == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    c = part[0] + part[1] + part[2] + part[3];
+    if (c) atomicAdd(count, c);
+  }
 }
 
 static int small_grid(int64_t items, int threads) {
@@ -234,8 +253,10 @@ ips_status launch_bitmap_fill(uint64_t* a, int64_t n_rows, int value, hipStream_
 ips_status launch_bitmap_count(const uint64_t* a, int64_t n_rows, int64_t* count, hipStream_t s) {
   IPS_HIP_TRY(hipMemsetAsync(count, 0, 8, s));
   if (n_rows <= 0) return IPS_OK;
-  hipLaunchKernelGGL(bitmap_count_kernel, dim3(small_grid((n_rows + 63) / 64, 256)), dim3(256), 0,
-                     s, a, n_rows, reinterpret_cast<unsigned long long*>(count));
+  int grid = small_grid((n_rows + 127) / 128, 256);
+  if (grid > device_cus() * 2) grid = device_cus() * 2;  // one atomic per block
+  hipLaunchKernelGGL(bitmap_count_kernel, dim3(grid), dim3(256), 0, s, a, n_rows,
+                     reinterpret_cast<unsigned long long*>(count));
   IPS_HIP_TRY(hipGetLastError());
   return IPS_OK;
 }
@@ -483,12 +504,11 @@ size_t scan_workspace_bytes(int64_t items) {
 }
 
 // ---- batch concatenation --------------------------------------------------------------------
-template <typename V>
-__global__ __launch_bounds__(kScanThreads) void batches_compact_kernel(
-    const V* __restrict__ batch_values, const uint32_t* __restrict__ counts, int64_t n_batches,
-    const uint64_t* __restrict__ block_offsets, V* __restrict__ dense) {
-  // one wave per batch inside a block of kScanItems batches; offsets via the block scan
-  __shared__ uint64_t offs[kScanItems];
+// Exclusive offset of every batch among all selected rows (block scan of the counts on top of the
+// scanned block totals); the per-batch kernels below then run one wave per batch.
+__global__ __launch_bounds__(kScanThreads) void batch_offsets_kernel(
+    const uint32_t* __restrict__ counts, int64_t n_batches,
+    const uint64_t* __restrict__ block_offsets, uint64_t* __restrict__ batch_off) {
   const int64_t base = (int64_t)blockIdx.x * kScanItems + (int64_t)threadIdx.x * kScanPerThread;
   uint32_t c[kScanPerThread];
   uint32_t v = 0;
@@ -501,20 +521,55 @@ __global__ __launch_bounds__(kScanThreads) void batches_compact_kernel(
   uint64_t off = block_offsets[blockIdx.x] + block_exclusive_scan(v, &total);
 #pragma unroll
   for (int e = 0; e < kScanPerThread; ++e) {
-    offs[threadIdx.x * kScanPerThread + e] = off;
+    if (base + e < n_batches) batch_off[base + e] = off;
     off += c[e];
   }
-  __syncthreads();
+}
+
+template <typename V>
+__global__ __launch_bounds__(kThreads) void batches_compact_kernel(
+    const V* __restrict__ batch_values, const uint32_t* __restrict__ counts, int64_t n_batches,
+    const uint64_t* __restrict__ batch_off, V* __restrict__ dense) {
   const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  for (int b = wave; b < kScanItems; b += kScanThreads / kWave) {
-    const int64_t batch = (int64_t)blockIdx.x * kScanItems + b;
-    if (batch >= n_batches) break;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t batch = (int64_t)blockIdx.x * kWavesPerBlock + wave_id(); batch < n_batches;
+       batch += stride) {
     const uint32_t cnt = counts[batch];
     const V* src = batch_values + batch * kRowsPerTile;
-    V* dst = dense + offs[b];
-    for (uint32_t i = lane; i < cnt; i += kWave) dst[i] = src[i];
+    V* dst = dense + batch_off[batch];
+    uint32_t i = lane;
+    for (; i + 3 * kWave < cnt; i += 4 * kWave) {  // four independent loads in flight per lane
+      V x0 = src[i], x1 = src[i + kWave], x2 = src[i + 2 * kWave], x3 = src[i + 3 * kWave];
+      dst[i] = x0; dst[i + kWave] = x1; dst[i + 2 * kWave] = x2; dst[i + 3 * kWave] = x3;
+    }
+    for (; i < cnt; i += kWave) dst[i] = src[i];
   }
+}
+
+size_t batches_workspace_bytes(int64_t n_batches) {
+  return scan_workspace_bytes(n_batches) + (size_t)(n_batches > 0 ? n_batches : 0) * 8 + 64;
+}
+
+// totals + per-batch offsets into the workspace; *total = number of selected rows
+static ips_status launch_batch_offsets(const uint32_t* counts, int64_t n_batches, int64_t* total,
+                                       void* workspace, uint64_t** batch_off, hipStream_t s) {
+  const int64_t nb = (n_batches + kScanItems - 1) / kScanItems;
+  uint64_t* totals = reinterpret_cast<uint64_t*>(workspace);
+  *batch_off = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(workspace) +
+                                           ((scan_workspace_bytes(n_batches) + 63) & ~(size_t)63));
+  hipLaunchKernelGGL((scan_block_totals_kernel<ArrayItems>), dim3((unsigned)nb),
+                     dim3(kScanThreads), 0, s, ArrayItems{counts}, n_batches, totals);
+  hipLaunchKernelGGL(scan_of_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, totals, nb, total);
+  hipLaunchKernelGGL(batch_offsets_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, s, counts,
+                     n_batches, totals, *batch_off);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+static int per_batch_grid(int64_t n_batches) {
+  int64_t want = (n_batches + kWavesPerBlock - 1) / kWavesPerBlock;
+  int64_t cap = (int64_t)device_cus() * 10 * grid_mult();
+  return (int)(want < cap ? want : cap);
 }
 
 ips_status launch_batches_compact(const void* batch_values, const uint32_t* counts,
@@ -524,19 +579,18 @@ ips_status launch_batches_compact(const void* batch_values, const uint32_t* coun
     IPS_HIP_TRY(hipMemsetAsync(total, 0, 8, s));
     return IPS_OK;
   }
-  const int64_t nb = (n_batches + kScanItems - 1) / kScanItems;
-  uint64_t* totals = reinterpret_cast<uint64_t*>(workspace);
-  hipLaunchKernelGGL((scan_block_totals_kernel<ArrayItems>), dim3((unsigned)nb),
-                     dim3(kScanThreads), 0, s, ArrayItems{counts}, n_batches, totals);
-  hipLaunchKernelGGL(scan_of_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, totals, nb, total);
+  uint64_t* batch_off = nullptr;
+  ips_status st = launch_batch_offsets(counts, n_batches, total, workspace, &batch_off, s);
+  if (st != IPS_OK) return st;
+  const int grid = per_batch_grid(n_batches);
   if (value_width == 4)
-    hipLaunchKernelGGL((batches_compact_kernel<uint32_t>), dim3((unsigned)nb), dim3(kScanThreads),
-                       0, s, reinterpret_cast<const uint32_t*>(batch_values), counts, n_batches,
-                       totals, reinterpret_cast<uint32_t*>(dense));
+    hipLaunchKernelGGL((batches_compact_kernel<uint32_t>), dim3(grid), dim3(kThreads), 0, s,
+                       reinterpret_cast<const uint32_t*>(batch_values), counts, n_batches,
+                       batch_off, reinterpret_cast<uint32_t*>(dense));
   else
-    hipLaunchKernelGGL((batches_compact_kernel<uint64_t>), dim3((unsigned)nb), dim3(kScanThreads),
-                       0, s, reinterpret_cast<const uint64_t*>(batch_values), counts, n_batches,
-                       totals, reinterpret_cast<uint64_t*>(dense));
+    hipLaunchKernelGGL((batches_compact_kernel<uint64_t>), dim3(grid), dim3(kThreads), 0, s,
+                       reinterpret_cast<const uint64_t*>(batch_values), counts, n_batches,
+                       batch_off, reinterpret_cast<uint64_t*>(dense));
   IPS_HIP_TRY(hipGetLastError());
   return IPS_OK;
 }
@@ -552,58 +606,85 @@ struct TupleCols {
   int32_t null_mask[IPS_TUPLE_MAX_COLS];
   int32_t n_cols;
   int32_t tuple_size;
+  const uint8_t* d_template;                    // wide tuples: device copy of the template tuple
+  uint32_t tmpl[32];                            // tuples <= 128 bytes: the template itself
 };
 
+constexpr int kTupleImageMax = 128;  // tuples up to this size are staged through LDS
+
 // Row-major tuples from per-column batches (AssembleRows, hdfs-parquet-scanner.cc:1151-1181).
-// One wave per batch; lane i handles tuple i, i+64, ... of the batch and writes each column's
-// slot; the batch's first tuple index comes from the block scan of the counts.
-__global__ __launch_bounds__(kScanThreads) void assemble_tuples_kernel(
+// One wave per batch, 64 tuples per round: lane i builds tuple i of the round in the wave's LDS
+// image (every column read is a coalesced 256/512-byte load of the batch), then the image -- 64
+// consecutive tuples = one contiguous piece of the output -- leaves as dword stores of consecutive
+// lanes.  Every tuple starts as a copy of the template tuple (InitTuple()).  IMAGE = false (tuples
+// wider than 128 bytes or not a multiple of 4): each lane copies the template and writes its slots
+// straight to HBM.
+template <bool IMAGE>
+__global__ __launch_bounds__(kThreads) void assemble_tuples_kernel(
     TupleCols tc, const uint32_t* __restrict__ counts, int64_t n_batches,
-    const uint64_t* __restrict__ block_offsets, uint8_t* __restrict__ tuples) {
-  __shared__ uint64_t offs[kScanItems];
-  const int64_t base = (int64_t)blockIdx.x * kScanItems + (int64_t)threadIdx.x * kScanPerThread;
-  uint32_t c[kScanPerThread];
-  uint32_t v = 0;
-#pragma unroll
-  for (int e = 0; e < kScanPerThread; ++e) {
-    c[e] = base + e < n_batches ? counts[base + e] : 0u;
-    v += c[e];
-  }
-  uint32_t total;
-  uint64_t off = block_offsets[blockIdx.x] + block_exclusive_scan(v, &total);
-#pragma unroll
-  for (int e = 0; e < kScanPerThread; ++e) {
-    offs[threadIdx.x * kScanPerThread + e] = off;
-    off += c[e];
-  }
-  __syncthreads();
+    const uint64_t* __restrict__ batch_off, uint8_t* __restrict__ tuples) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t image_all[];  // IMAGE: 4 waves x 64 tuples
   const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  for (int b = wave; b < kScanItems; b += kScanThreads / kWave) {
-    const int64_t batch = (int64_t)blockIdx.x * kScanItems + b;
-    if (batch >= n_batches) break;
+  const int wave = wave_id();
+  const int ts = tc.tuple_size;
+  uint8_t* image = image_all + (IMAGE ? wave * kWave * ts : 0);
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t batch = (int64_t)blockIdx.x * kWavesPerBlock + wave; batch < n_batches;
+       batch += stride) {
     const uint32_t cnt = counts[batch];
-    uint8_t* dst = tuples + offs[b] * (uint64_t)tc.tuple_size;
-    for (uint32_t i = lane; i < cnt; i += kWave) {
-      uint8_t* t = dst + (uint64_t)i * tc.tuple_size;
-      const uint64_t gi = offs[b] + i;  // index of this tuple among all selected rows
-      for (int col = 0; col < tc.n_cols; ++col) {
-        uint64_t src = (uint64_t)batch * kRowsPerTile + i;
-        if (tc.flags[col]) {  // OPTIONAL column: NULL bit, or the rank-th dense value
-          const uint64_t fw = tc.flags[col][gi >> 6];
-          if (!((fw >> (gi & 63)) & 1ull)) {
-            t[tc.null_byte[col]] |= (uint8_t)tc.null_mask[col];
-            continue;
+    const uint64_t first = batch_off[batch];
+    for (uint32_t i0 = 0; i0 < cnt; i0 += kWave) {
+      const uint32_t i = i0 + lane;
+      const uint32_t in_round = cnt - i0 < (uint32_t)kWave ? cnt - i0 : (uint32_t)kWave;
+      uint8_t* t = IMAGE ? image + lane * ts : tuples + (first + i) * (uint64_t)ts;
+      if (IMAGE) {
+#pragma unroll
+        for (int d = 0; d < kTupleImageMax / 4; ++d)
+          if (4 * d < ts) reinterpret_cast<uint32_t*>(t)[d] = tc.tmpl[d];
+      } else if (i < cnt) {
+        for (int d = 0; d < ts; ++d) t[d] = tc.d_template[d];
+      }
+      if (i < cnt) {
+        const uint64_t gi = first + i;  // index of this tuple among all selected rows
+        for (int col = 0; col < tc.n_cols; ++col) {
+          uint64_t src = (uint64_t)batch * kRowsPerTile + i;
+          if (tc.flags[col]) {  // OPTIONAL column: NULL bit, or the rank-th dense value
+            const uint64_t fw = tc.flags[col][gi >> 6];
+            if (!((fw >> (gi & 63)) & 1ull)) {
+              t[tc.null_byte[col]] |= (uint8_t)tc.null_mask[col];
+              continue;
+            }
+            src = tc.prefix[col][gi >> 6] + __builtin_popcountll(fw & ((1ull << (gi & 63)) - 1ull));
           }
-          src = tc.prefix[col][gi >> 6] + __builtin_popcountll(fw & ((1ull << (gi & 63)) - 1ull));
+          uint8_t* slot = t + tc.offset[col];
+          const bool aligned = ((tc.offset[col] | ts) & 3) == 0;  // slots are naturally aligned in Impala tuples
+          if (tc.width[col] == 4) {
+            const uint32_t x = reinterpret_cast<const uint32_t*>(tc.values[col])[src];
+            if (aligned) *reinterpret_cast<uint32_t*>(slot) = x;
+            else __builtin_memcpy(slot, &x, 4);
+          } else {
+            const uint64_t x = reinterpret_cast<const uint64_t*>(tc.values[col])[src];
+            if (aligned) {
+              reinterpret_cast<uint32_t*>(slot)[0] = (uint32_t)x;
+              reinterpret_cast<uint32_t*>(slot)[1] = (uint32_t)(x >> 32);
+            } else {
+              __builtin_memcpy(slot, &x, 8);
+            }
+          }
         }
-        if (tc.width[col] == 4) {
-          const uint32_t x = reinterpret_cast<const uint32_t*>(tc.values[col])[src];
-          __builtin_memcpy(t + tc.offset[col], &x, 4);
+      }
+      if (IMAGE) {
+        wave_lds_fence();
+        uint8_t* dst = tuples + (first + i0) * (uint64_t)ts;
+        const uint32_t bytes = in_round * (uint32_t)ts;
+        if ((ts & 15) == 0) {  // 16-byte pieces: the destination is 16-byte aligned as well
+          for (uint32_t o = lane * 16; o < bytes; o += kWave * 16)
+            *reinterpret_cast<u32x4*>(dst + o) = *reinterpret_cast<const u32x4*>(image + o);
         } else {
-          const uint64_t x = reinterpret_cast<const uint64_t*>(tc.values[col])[src];
-          __builtin_memcpy(t + tc.offset[col], &x, 8);
+          for (uint32_t o = lane * 4; o < bytes; o += kWave * 4)
+            *reinterpret_cast<uint32_t*>(dst + o) = *reinterpret_cast<const uint32_t*>(image + o);
         }
+        wave_lds_fence();
       }
     }
   }
@@ -612,13 +693,14 @@ __global__ __launch_bounds__(kScanThreads) void assemble_tuples_kernel(
 size_t scan_workspace_bytes(int64_t items);
 size_t assemble_workspace_bytes(int64_t n_batches, int n_optional) {
   const int64_t flag_words = (n_batches * kRowsPerTile + 63) / 64;
-  return scan_workspace_bytes(n_batches) +
-         (size_t)n_optional * (scan_workspace_bytes(flag_words) + (size_t)flag_words * 8) + 64;
+  return batches_workspace_bytes(n_batches) +
+         (size_t)n_optional * (scan_workspace_bytes(flag_words) + (size_t)flag_words * 8) + 64 +
+         4096;  // + device copy of a wide template tuple
 }
 
 ips_status launch_assemble_tuples(const ips_tuple_column* cols, int n_cols, const uint32_t* counts,
-                                  int64_t n_batches, int tuple_size, void* tuples, int64_t* total,
-                                  void* workspace, hipStream_t s) {
+                                  int64_t n_batches, int tuple_size, const void* h_template,
+                                  void* tuples, int64_t* total, void* workspace, hipStream_t s) {
   if (n_batches <= 0) {
     IPS_HIP_TRY(hipMemsetAsync(total, 0, 8, s));
     return IPS_OK;
@@ -627,10 +709,11 @@ ips_status launch_assemble_tuples(const ips_tuple_column* cols, int n_cols, cons
   memset(&tc, 0, sizeof(tc));
   tc.n_cols = n_cols;
   tc.tuple_size = tuple_size;
-  // workspace: [batch scan totals][per OPTIONAL column: flag-word scan totals + per-word prefix]
+  // workspace: [batch scan totals + batch offsets][per OPTIONAL column: flag-word scan totals +
+  // per-word prefix]
   const int64_t n_rows_cap = n_batches * kRowsPerTile;
   const int64_t flag_words = (n_rows_cap + 63) / 64;
-  uint8_t* ws = reinterpret_cast<uint8_t*>(workspace) + scan_workspace_bytes(n_batches);
+  uint8_t* ws = reinterpret_cast<uint8_t*>(workspace) + batches_workspace_bytes(n_batches);
   for (int i = 0; i < n_cols; ++i) {
     tc.width[i] = cols[i].value_width;
     tc.offset[i] = cols[i].tuple_offset;
@@ -656,13 +739,29 @@ ips_status launch_assemble_tuples(const ips_tuple_column* cols, int n_cols, cons
       tc.values[i] = cols[i].d_batch_values;
     }
   }
-  const int64_t nb = (n_batches + kScanItems - 1) / kScanItems;
-  uint64_t* totals = reinterpret_cast<uint64_t*>(workspace);
-  hipLaunchKernelGGL((scan_block_totals_kernel<ArrayItems>), dim3((unsigned)nb),
-                     dim3(kScanThreads), 0, s, ArrayItems{counts}, n_batches, totals);
-  hipLaunchKernelGGL(scan_of_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, totals, nb, total);
-  hipLaunchKernelGGL(assemble_tuples_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, s, tc,
-                     counts, n_batches, totals, reinterpret_cast<uint8_t*>(tuples));
+  const bool image = tuple_size <= kTupleImageMax && tuple_size % 4 == 0;
+  if (image) {
+    if (h_template) memcpy(tc.tmpl, h_template, (size_t)tuple_size);
+  } else {  // ws now points behind the last OPTIONAL column's scratch
+    if (tuple_size > 4096) {
+      set_error("ips_assemble_tuples: tuple_size %d > 4096", tuple_size);
+      return IPS_ERR_UNSUPPORTED;
+    }
+    if (h_template) IPS_HIP_TRY(hipMemcpyAsync(ws, h_template, (size_t)tuple_size, hipMemcpyHostToDevice, s));
+    else IPS_HIP_TRY(hipMemsetAsync(ws, 0, (size_t)tuple_size, s));
+    tc.d_template = ws;
+  }
+  uint64_t* batch_off = nullptr;
+  ips_status st = launch_batch_offsets(counts, n_batches, total, workspace, &batch_off, s);
+  if (st != IPS_OK) return st;
+  const int grid = per_batch_grid(n_batches);
+  if (image)
+    hipLaunchKernelGGL(assemble_tuples_kernel<true>, dim3(grid), dim3(kThreads),
+                       (size_t)kWavesPerBlock * kWave * tuple_size, s, tc, counts, n_batches,
+                       batch_off, reinterpret_cast<uint8_t*>(tuples));
+  else
+    hipLaunchKernelGGL(assemble_tuples_kernel<false>, dim3(grid), dim3(kThreads), 0, s, tc, counts,
+                       n_batches, batch_off, reinterpret_cast<uint8_t*>(tuples));
   IPS_HIP_TRY(hipGetLastError());
   return IPS_OK;
 }

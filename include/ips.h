@@ -145,8 +145,9 @@ ips_status ips_batches_compact(const void* d_batch_values, const uint32_t* d_bat
  * at tuple + slot_desc->tuple_offset(); descriptors.h:60-71, 75-95).  All columns were
  * materialised against the SAME bitmap (ips_fle_select / ips_dict_scan / ips_fle_scan), so they
  * share d_batch_counts.  Tuple i (i-th selected row, row order) is written at
- * d_tuples + i*tuple_size; bytes not covered by a slot are left untouched (InitTuple copies a
- * template tuple first in the reference).  d_total receives the tuple count.
+ * d_tuples + i*tuple_size and starts as a copy of h_template_tuple (tuple_size bytes on the host:
+ * the scanner's template_tuple_ that InitTuple() copies first, hdfs-scanner.h; NULL = all zero), so
+ * every byte of every tuple is defined.  d_total receives the tuple count.
  * Workspace: ips_assemble_workspace_bytes(n_rows, number of OPTIONAL columns). */
 typedef struct {
   const void* d_batch_values; /* batches of IPS_BATCH_ROWS slots of value_width bytes */
@@ -157,7 +158,7 @@ typedef struct {
    * by ips_bitmap_compress(nonnull, selection) + ips_batches_compact); d_nonnull_flags has one bit
    * per selected row (ips_bitmap_compress(selection, nonnull)).  A NULL row gets
    * tuple[null_byte_offset] |= null_bit_mask (SlotDescriptor::null_indicator_offset(),
-   * descriptors.h:60-71) and its slot is left untouched. */
+   * descriptors.h:60-71) and its slot keeps the template's bytes. */
   const void* d_dense_values;
   const uint64_t* d_nonnull_flags;
   int32_t null_byte_offset;
@@ -167,8 +168,8 @@ typedef struct {
 size_t ips_assemble_workspace_bytes(int64_t n_rows, int n_optional_cols);
 ips_status ips_assemble_tuples(const ips_tuple_column* cols, int n_cols,
                                const uint32_t* d_batch_counts, int64_t n_rows, int tuple_size,
-                               void* d_tuples, int64_t* d_total, void* d_workspace,
-                               ips_stream stream);
+                               const void* h_template_tuple, void* d_tuples, int64_t* d_total,
+                               void* d_workspace, ips_stream stream);
 
 /* ---- sorted dictionary codec ---------------------------------------------------------------- */
 /* DictDecoder<T>::DictDecoder(dict_buffer, dict_len, fixed_len_size), dict-encoding.h:449-459:

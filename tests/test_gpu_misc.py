@@ -278,6 +278,25 @@ def test_assemble_tuples(capi, O):
     assert np.array_equal(t[:, 8:16].copy().view(np.int64).ravel(), d64[codes][sel])
     assert np.array_equal(t[:, 16:20].copy().view(np.uint32).ravel(), c[sel])
     assert not t[:, 4:8].any() and not t[:, 20:24].any()
+    # InitTuple(): every tuple starts as a copy of the template tuple; slots overwrite it
+    tmpl = rng.integers(1, 255, tuple_size).astype(np.uint8)
+    t = capi.assemble_tuples([(va, 0), (v64, 8), (vc, 16)], counts, n, tuple_size, template=tmpl).cpu().numpy()
+    assert np.array_equal(t[:, 0:4].copy().view(np.uint32).ravel(), a[sel])
+    assert np.array_equal(t[:, 16:20].copy().view(np.uint32).ravel(), c[sel])
+    assert (t[:, 4:8] == tmpl[4:8]).all() and (t[:, 20:24] == tmpl[20:24]).all()
+    # tuple layouts off the staged path: odd size, unaligned slots (direct writes), wide tuples
+    for size, offs in ((23, (1, 11, 19)), (200, (4, 104, 196)), (132, (0, 64, 128))):
+        tmpl = rng.integers(1, 255, size).astype(np.uint8)
+        t = capi.assemble_tuples([(va, offs[0]), (v64, offs[1]), (vc, offs[2])], counts, n, size,
+                                 template=tmpl).cpu().numpy()
+        assert t.shape == (int(sel.sum()), size)
+        assert np.array_equal(t[:, offs[0]:offs[0] + 4].copy().view(np.uint32).ravel(), a[sel])
+        assert np.array_equal(t[:, offs[1]:offs[1] + 8].copy().view(np.int64).ravel(), d64[codes][sel])
+        assert np.array_equal(t[:, offs[2]:offs[2] + 4].copy().view(np.uint32).ravel(), c[sel])
+        covered = np.zeros(size, bool)
+        for o, w in ((offs[0], 4), (offs[1], 8), (offs[2], 4)):
+            covered[o:o + w] = True
+        assert (t[:, ~covered] == tmpl[~covered]).all()
     dd.close()
 
 
