@@ -352,20 +352,47 @@ __global__ __launch_bounds__(kScanThreads) void scan_of_totals_kernel(uint64_t* 
 }
 
 // ---- IntersectBitset ------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t deposit_bits(uint64_t src, uint64_t mask) {
-  uint64_t out = 0;
-  while (mask) {  // j-th set bit of mask takes bit j of src
-    uint64_t low = mask & (0ull - mask);
-    if (src & 1ull) out |= low;
-    src >>= 1;
-    mask ^= low;
+// Bit deposit / extract of a 64-bit word (pdep / pext), four mask bits at a time through a 256-entry
+// table in LDS: entry [mask4 << 4 | src4] = the nibble's result.  16 independent table reads per
+// word instead of a loop of up to 64 dependent steps.
+__device__ __forceinline__ void nibble_tables_init(uint8_t* dep, uint8_t* ext) {
+  // called by all kScanThreads (= 256) threads: one entry each
+  const uint32_t m = threadIdx.x >> 4, v = threadIdx.x & 15u;
+  uint32_t d = 0, e = 0, j = 0;
+#pragma unroll
+  for (uint32_t bit = 0; bit < 4; ++bit) {
+    if (m & (1u << bit)) {
+      if (v & (1u << j)) d |= 1u << bit;   // deposit: j-th source bit goes to mask position 'bit'
+      if (v & (1u << bit)) e |= 1u << j;   // extract: source bit at 'bit' becomes result bit j
+      ++j;
+    }
   }
-  return out;
+  dep[threadIdx.x] = (uint8_t)d;
+  ext[threadIdx.x] = (uint8_t)e;
+  __syncthreads();
+}
+
+__device__ __forceinline__ uint64_t deposit_bits(uint64_t src, uint64_t mask, const uint8_t* dep) {
+  uint32_t out[2] = {0u, 0u};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t mh = (uint32_t)(mask >> (32 * h));
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const uint32_t m4 = (mh >> (4 * n)) & 15u;
+      const uint32_t r = dep[(m4 << 4) | ((uint32_t)src & 15u)];
+      out[h] |= r << (4 * n);
+      src >>= __builtin_popcount(m4);
+    }
+  }
+  return (uint64_t)out[0] | ((uint64_t)out[1] << 32);
 }
 
 __global__ __launch_bounds__(kScanThreads) void bitmap_expand_kernel(
     const uint64_t* __restrict__ root, const uint64_t* __restrict__ sub, int64_t n_rows,
     const uint64_t* __restrict__ block_offsets, uint64_t* __restrict__ out) {
+  __shared__ uint8_t dep_lut[256], ext_lut[256];
+  nibble_tables_init(dep_lut, ext_lut);
   const int64_t n_words = (n_rows + 63) / 64;
   const int64_t base = (int64_t)blockIdx.x * kScanItems + (int64_t)threadIdx.x * kScanPerThread;
   PopcItems items{root, n_rows};
@@ -390,7 +417,7 @@ __global__ __launch_bounds__(kScanThreads) void bitmap_expand_kernel(
         bits = sub[off >> 6] >> sh;
         if (sh + (int)pc[e] > 64) bits |= sub[(off >> 6) + 1] << (64 - sh);
       }
-      out[base + e] = deposit_bits(bits, m);
+      out[base + e] = deposit_bits(bits, m, dep_lut);
       off += pc[e];
     }
   }
@@ -413,14 +440,19 @@ ips_status launch_bitmap_expand(const uint64_t* root, const uint64_t* sub, int64
 }
 
 // ---- bitmap compress (inverse of IntersectBitset) ---------------------------------------------
-__device__ __forceinline__ uint64_t extract_bits(uint64_t src, uint64_t mask) {
+__device__ __forceinline__ uint64_t extract_bits(uint64_t src, uint64_t mask, const uint8_t* ext) {
   uint64_t out = 0;
-  int j = 0;
-  while (mask) {  // bit j of the result = src at the j-th set bit of mask
-    uint64_t low = mask & (0ull - mask);
-    if (src & low) out |= 1ull << j;
-    ++j;
-    mask ^= low;
+  uint32_t pos = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t mh = (uint32_t)(mask >> (32 * h)), sh = (uint32_t)(src >> (32 * h));
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const uint32_t m4 = (mh >> (4 * n)) & 15u;
+      const uint32_t r = ext[(m4 << 4) | ((sh >> (4 * n)) & 15u)];
+      out |= (uint64_t)r << pos;
+      pos += __builtin_popcount(m4);
+    }
   }
   return out;
 }
@@ -428,6 +460,8 @@ __device__ __forceinline__ uint64_t extract_bits(uint64_t src, uint64_t mask) {
 __global__ __launch_bounds__(kScanThreads) void bitmap_compress_kernel(
     const uint64_t* __restrict__ mask, const uint64_t* __restrict__ src, int64_t n_rows,
     const uint64_t* __restrict__ block_offsets, unsigned long long* __restrict__ out) {
+  __shared__ uint8_t dep_lut[256], ext_lut[256];
+  nibble_tables_init(dep_lut, ext_lut);
   const int64_t n_words = (n_rows + 63) / 64;
   const int64_t base = (int64_t)blockIdx.x * kScanItems + (int64_t)threadIdx.x * kScanPerThread;
   PopcItems items{mask, n_rows};
@@ -446,7 +480,7 @@ __global__ __launch_bounds__(kScanThreads) void bitmap_compress_kernel(
       uint64_t m = mask[base + e];
       int64_t valid = n_rows - (base + e) * 64;
       if (valid < 64) m &= (1ull << valid) - 1ull;
-      const uint64_t bits = extract_bits(src[base + e], m);
+      const uint64_t bits = extract_bits(src[base + e], m, ext_lut);
       const int sh = (int)(off & 63);
       if (bits) {  // neighbouring threads share output words: OR the pieces in (out is zeroed)
         atomicOr(out + (off >> 6), bits << sh);
