@@ -9,7 +9,7 @@
 
 namespace ips {
 
-enum ScanMode { kScanPredicate = 0, kScanGivenBitmap = 1, kScanInList = 2 };
+enum ScanMode { kScanPredicate = 0, kScanGivenBitmap = 1, kScanInList = 2, kScanInTable = 3 };
 
 // Dictionary gather applied while values leave LDS: G = 0 none (store the code / raw value),
 // 4 / 8 = bytes per dictionary entry.
@@ -27,6 +27,38 @@ struct DictLds {
   static constexpr bool kUse = G != 0 && W <= 12 && ((1 << (W <= 12 ? W : 0)) * G) <= 4096;
   static constexpr int kEntries = kUse ? (1 << (W <= 12 ? W : 0)) : 1;
 };
+
+// Long IN lists on narrow columns (every dictionary code width): membership becomes a 2^W-bit set
+// in LDS, built once per workgroup, and each decoded value costs one LDS read -- independent of
+// the list length -- instead of W bit-select steps per constant.
+constexpr int kInTableMinConsts = 10;  // below this the K*W plane steps are cheaper (host-side choice)
+template <int W>
+struct InTable {
+  static constexpr bool kUse = W <= 16;
+  static constexpr int kDwords = kUse ? ((1 << (W <= 16 ? W : 0)) + 31) / 32 : 1;
+};
+
+template <int W>
+__device__ __forceinline__ void in_table_build(uint32_t* table, const PredArgs& args) {
+  for (int i = threadIdx.x; i < InTable<W>::kDwords; i += kThreads) table[i] = 0u;
+  __syncthreads();
+  for (int j = threadIdx.x; j < args.n_consts; j += kThreads) {
+    const uint32_t c = args.consts[j];
+    atomicOr(&table[c >> 5], 1u << (c & 31u));
+  }
+  __syncthreads();
+}
+
+// bit j of the result <-> row j of the half-block (LSB first)
+__device__ __forceinline__ uint32_t in_table_lookup(const uint32_t* table, const uint32_t (&v)[32]) {
+  uint32_t w[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) w[j] = table[v[j] >> 5];
+  uint32_t bm = 0u;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) bm |= ((w[j] >> (v[j] & 31u)) & 1u) << j;
+  return bm;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Fused scan: predicate (or given bitmap) -> bitmap, selected rows decoded and written per batch.
@@ -56,6 +88,9 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kerne
     if constexpr (DictLds<W, G>::kUse) return dict_lds[code];
     else return dict[code];
   };
+  constexpr bool kInTable = MODE == kScanInTable && InTable<W>::kUse;
+  __shared__ uint32_t in_table[kInTable ? InTable<W>::kDwords : 1];
+  if constexpr (kInTable) in_table_build<W>(in_table, args);
 
   const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   const int64_t total_words = ((n_rows + 63) / 64) * W;
@@ -79,6 +114,12 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kerne
     }
     uint32_t p[W];
     planes_from_lds<W>(lds32, lane, p);
+    uint32_t v[32];
+    if (kInTable) {  // long list: decode first, one set lookup per value
+      planes_to_values<W>(p, v);
+      bm = finish_bitmap_dword(bitrev32(in_table_lookup(in_table, v)), tile, lane, n_rows);
+      if (d < bm_dwords) bitmap32[d] = bm;
+    }
     if (MODE == kScanInList && W <= 16) {
       bm = finish_bitmap_dword(pred_in_from_regs<W>(p, args.consts, args.n_consts), tile, lane, n_rows);
       if (d < bm_dwords) bitmap32[d] = bm;
@@ -94,8 +135,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kerne
 
     uint32_t count = 0;
     if (__builtin_amdgcn_ballot_w64(bm != 0u) != 0ull) {  // wave-uniform: any row selected
-      uint32_t v[32];
-      planes_to_values<W>(p, v);
+      if (!kInTable) planes_to_values<W>(p, v);
       const uint32_t mine = (uint32_t)__builtin_popcount(bm);
       const uint32_t incl = wave_inclusive_scan(mine);
       count = __builtin_amdgcn_readlane(incl, 63);
@@ -165,7 +205,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kerne
 // instead of once more for the AND), args.join evaluates a second comparison on the same column
 // in the same pass (BETWEEN).
 // ---------------------------------------------------------------------------------------------
-enum PredKind { kPredSingle = 0, kPredPair = 1, kPredInList = 2 };
+enum PredKind { kPredSingle = 0, kPredPair = 1, kPredInList = 2, kPredInTable = 3 };
 
 template <int W, int KIND>
 __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_w_kernel(
@@ -182,6 +222,10 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_w_ker
   const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
   const int64_t bm_dwords = bitmap_dwords(n_rows);
   int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  constexpr bool kInTable = KIND == kPredInTable && InTable<W>::kUse;
+  __shared__ uint32_t in_table[kInTable ? InTable<W>::kDwords : 1];
+  if constexpr (kInTable) in_table_build<W>(in_table, args);
+
   u32x4 r[L];
   if (tile < tiles) tile_load<L>(enc, tile, W, total_words, lane, r);
   while (tile < tiles) {
@@ -198,6 +242,12 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_w_ker
       uint32_t r1, r2;
       pred_pair_from_lds(lds32, W, lane, args.op, args.consts[0], args.op2, args.const2, &r1, &r2);
       sel = args.join == 1 ? (r1 & r2) : (r1 | r2);
+    } else if (kInTable) {
+      uint32_t p[W];
+      planes_from_lds<W>(lds32, lane, p);
+      uint32_t v[32];
+      planes_to_values<W>(p, v);
+      sel = bitrev32(in_table_lookup(in_table, v));
     } else if (W <= 16) {
       uint32_t p[W];
       planes_from_lds<W>(lds32, lane, p);

@@ -37,13 +37,22 @@ static ips_status launch_w(int mode, int gather, const uint64_t* enc, int64_t n_
                  dict_entries, bad_index, s
   if (gather == 0) {
     if (mode == kScanPredicate) return launch_one<W, kScanPredicate, 0>(IPS_ARGS);
-    if (mode == kScanInList) return launch_one<W, kScanInList, 0>(IPS_ARGS);
+    if (mode == kScanInList) {
+      if constexpr (W <= 16) {
+        if (args.n_consts >= kInTableMinConsts) return launch_one<W, kScanInTable, 0>(IPS_ARGS);
+      }
+      return launch_one<W, kScanInList, 0>(IPS_ARGS);
+    }
     return launch_one<W, kScanGivenBitmap, 0>(IPS_ARGS);
   }
   if constexpr (W <= 16) {  // dictionaries hold <= 40000 entries: codes are <= 16 bits wide
     if (mode == kScanPredicate) {
       if (gather == 4) return launch_one<W, kScanPredicate, 4>(IPS_ARGS);
       if (gather == 8) return launch_one<W, kScanPredicate, 8>(IPS_ARGS);
+    }
+    if (mode == kScanInList && args.n_consts >= kInTableMinConsts) {
+      if (gather == 4) return launch_one<W, kScanInTable, 4>(IPS_ARGS);
+      if (gather == 8) return launch_one<W, kScanInTable, 8>(IPS_ARGS);
     }
     if (mode == kScanInList) {
       if (gather == 4) return launch_one<W, kScanInList, 4>(IPS_ARGS);
@@ -92,7 +101,12 @@ template <int W>
 static ips_status launch_pred_w(const uint64_t* enc, int64_t n_rows, const PredArgs& args,
                                 uint32_t* bitmap32, hipStream_t s) {
   if (args.join != 0) return launch_pred_wk<W, kPredPair>(enc, n_rows, args, bitmap32, s);
-  if (args.op == 5) return launch_pred_wk<W, kPredInList>(enc, n_rows, args, bitmap32, s);
+  if (args.op == 5) {
+    if constexpr (W <= 16) {
+      if (args.n_consts >= kInTableMinConsts) return launch_pred_wk<W, kPredInTable>(enc, n_rows, args, bitmap32, s);
+    }
+    return launch_pred_wk<W, kPredInList>(enc, n_rows, args, bitmap32, s);
+  }
   return launch_pred_wk<W, kPredSingle>(enc, n_rows, args, bitmap32, s);
 }
 

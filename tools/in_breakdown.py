@@ -14,7 +14,7 @@ ips = entry.load_package()
 capi = ips.capi
 n = 1 << 28
 dev = torch.device("cuda")
-for bw in (8, 12):
+for bw in (8, 12, 16):
     vals = capi.synth_u32(ips.synth.SEED_HEADLINE, n, bw)
     enc = capi.fle_encode(vals, bw)
     outs = capi.alloc_scan_outputs(n, dev)
@@ -23,7 +23,9 @@ for bw in (8, 12):
     dd = capi.Dict(page.view(np.uint8), 2)   # T_INT32
     tmin, tmed = timeit(lambda: dd.decode(enc, n, bw))
     print(f"w={bw:2d}      dict decode (gather every row)      min {tmin*1e3:7.1f} us  med {tmed*1e3:7.1f} us", flush=True)
-    for K in (1, 4, 16):
+    for K in (4, 16, 17, 64, 256):
+        if K > D:
+            continue
         codes = [int(x) for x in np.linspace(1, D - 2, K).astype(int)]
         lits = [c * 3 for c in codes]
         rows = []
