@@ -215,6 +215,35 @@ def main():
             graph_us = None
             print(f"bench.py: hipGraph capture skipped: {ex}", file=sys.stderr)
 
+    # ---- the same column as 256 SEPARATE 2^20-row page buffers, ips_fle_scan_pages -----------
+    pages_info = None
+    if rank == 0 and n >= n1 and n % n1 == 0 and not gather:
+        try:
+            n_pages = n // n1
+            wpp = n1 // 64 * bw
+            pages = [(enc[p * wpp:(p + 1) * wpp].clone(), n1, capi.alloc_scan_outputs(n1, dev))
+                     for p in range(n_pages)]
+            plist = capi.make_page_list(pages)
+            for _ in range(3):
+                capi.fle_scan_pages(plist, bw, capi.OP_LT, c)
+            pe = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                  for _ in range(10)]
+            torch.cuda.synchronize()
+            for a, b in pe:
+                a.record(stream)
+                capi.fle_scan_pages(plist, bw, capi.OP_LT, c)
+                b.record(stream)
+            torch.cuda.synchronize()
+            ptimes = sorted(a.elapsed_time(b) for a, b in pe)
+            same = all(torch.equal(pages[p][2][0][:n1 // 64], local_bm[0][p * n1 // 64:(p + 1) * n1 // 64])
+                       for p in (0, n_pages // 2, n_pages - 1))
+            pages_info = {"pages": n_pages, "rows_per_page": n1,
+                          "us_per_step_median": round(ptimes[len(ptimes) // 2] * 1e3, 1),
+                          "launches_per_step": (n_pages + 63) // 64, "bitmaps_equal_contiguous_run": same}
+            del pages, plist
+        except Exception as ex:  # dev information only
+            print(f"bench.py: separate-pages leg skipped: {ex}", file=sys.stderr)
+
     if rank != 0:
         if gather:
             dist.destroy_process_group()
@@ -291,6 +320,7 @@ def main():
         "extra": {"check": check, "selected_rows": n_sel,
                   "latency": {"rows": n1, "us_per_launch_back_to_back": lat_us and round(lat_us, 2),
                               "us_per_launch_hipgraph_replay": graph_us and round(graph_us, 2)},
+                  "separate_pages": pages_info,
                   "device": capi.device_info()[0]},
     }
     if gather:

@@ -36,7 +36,7 @@ SYMBOLS = [
     "ips_malloc", "ips_free", "ips_memcpy_h2d", "ips_memcpy_d2h", "ips_memset",
     "ips_stream_create", "ips_stream_destroy", "ips_stream_synchronize",
     "ips_fle_encoded_bytes", "ips_fle_encode", "ips_fle_decode", "ips_fle_pred", "ips_fle_scan",
-    "ips_fle_select", "ips_batches_workspace_bytes", "ips_batches_compact", "ips_assemble_tuples",
+    "ips_fle_select", "ips_fle_scan_pages", "ips_batches_workspace_bytes", "ips_batches_compact", "ips_assemble_tuples",
     "ips_assemble_workspace_bytes", "ips_bitmap_compress",
     "ips_dict_open", "ips_dict_close", "ips_dict_num_entries", "ips_dict_bit_width", "ips_dict_encode",
     "ips_dict_translate", "ips_dict_pred", "ips_dict_decode", "ips_dict_scan", "ips_dict_select",
@@ -191,6 +191,28 @@ def fle_scan(enc, n_rows, bw, op, values, outputs=None, stream=None):
     _ck(lib().ips_fle_scan(_ptr(enc), C.c_int64(n_rows), bw, op, p, k, _ptr(bitmap), _ptr(bvals),
                            _ptr(counts), _stream(stream)))
     return bitmap[:_words(n_rows)], bvals, counts[:n_batches(n_rows)]
+
+
+class PageScan(C.Structure):
+    _fields_ = [("d_enc", C.c_void_p), ("n_rows", C.c_int64), ("d_bitmap", C.c_void_p),
+                ("d_batch_values", C.c_void_p), ("d_batch_counts", C.c_void_p)]
+
+
+def make_page_list(pages):
+    """pages: list of (enc tensor, n_rows, (bitmap, batch_values, batch_counts)).  -> ctypes array
+    (build it once per column chunk; ips_fle_scan_pages reads it on the host at every call)."""
+    arr = (PageScan * len(pages))()
+    for i, (enc, n_rows, outs) in enumerate(pages):
+        arr[i].d_enc = enc.data_ptr()
+        arr[i].n_rows = n_rows
+        arr[i].d_bitmap, arr[i].d_batch_values, arr[i].d_batch_counts = (t.data_ptr() for t in outs)
+    return arr
+
+
+def fle_scan_pages(page_list, bw, op, values, stream=None):
+    """ips_fle_scan over a list of separate pages (make_page_list) in ceil(n/64) launches."""
+    keep, p, k = _consts(values)
+    _ck(lib().ips_fle_scan_pages(page_list, len(page_list), bw, op, p, k, _stream(stream)))
 
 
 def fle_select(enc, n_rows, bw, bitmap, outputs=None, stream=None):

@@ -91,7 +91,9 @@ int grid_for_tiles(const void* kernel, int64_t tiles) {
                                         const void*, uint32_t, int32_t*, hipStream_t);          \
   ips_status launch_fle_encode_part_##P(int, int, const void*, int64_t, uint64_t*, hipStream_t); \
   ips_status launch_fle_pred_part_##P(int, const uint64_t*, int64_t, const PredArgs&, uint32_t*, \
-                                      hipStream_t);
+                                      hipStream_t);                                             \
+  ips_status launch_fle_scan_pages_part_##P(int, const PageBatch&, int, int64_t,                \
+                                            const PredArgs&, hipStream_t);
 IPS_DECL_PARTS(a) IPS_DECL_PARTS(b) IPS_DECL_PARTS(c) IPS_DECL_PARTS(d)
 
 ips_status launch_bitmap_binop(int op, uint64_t* a, const uint64_t* b, int64_t n_words, hipStream_t s);
@@ -352,6 +354,57 @@ ips_status ips_fle_select(const void* d_enc, int64_t n_rows, int bit_width,
   return launch_fle_scan(bit_width, kScanGivenBitmap, 0, reinterpret_cast<const uint64_t*>(d_enc),
                          n_rows, args, nullptr, reinterpret_cast<const uint32_t*>(d_bitmap),
                          d_batch_values, d_batch_counts, nullptr, 0, nullptr, S(stream));
+}
+
+ips_status ips_fle_scan_pages(const ips_page_scan* h_pages, int n_pages, int bit_width, ips_op op,
+                              const uint64_t* consts, int n_consts, ips_stream stream) {
+  IPS_REQUIRE(n_pages >= 0, "ips_fle_scan_pages: n_pages < 0");
+  IPS_REQUIRE(op != IPS_OP_IN, "ips_fle_scan_pages: IN lists go page by page through ips_fle_scan");
+  PredArgs args;
+  ConstKind kind;
+  ips_status st = build_pred_args(bit_width, op, consts, n_consts, &args, &kind, "ips_fle_scan_pages");
+  if (st != IPS_OK) return st;
+  if (n_pages == 0) return IPS_OK;
+  IPS_REQUIRE(h_pages != nullptr, "ips_fle_scan_pages: NULL page list");
+  for (int i = 0; i < n_pages; ++i) {
+    const ips_page_scan& pg = h_pages[i];
+    if (!check_fle_common(pg.d_enc, pg.n_rows, bit_width, "ips_fle_scan_pages")) return IPS_ERR_INVALID_ARG;
+    IPS_REQUIRE(pg.n_rows == 0 || (pg.d_bitmap && aligned16(pg.d_bitmap) && pg.d_batch_values &&
+                                   aligned16(pg.d_batch_values) && pg.d_batch_counts),
+                "ips_fle_scan_pages: page %d: NULL or misaligned output", i);
+  }
+  hipStream_t s = S(stream);
+  if (kind != kEvaluate) {  // a constant outside the domain: the answer does not depend on the data
+    for (int i = 0; i < n_pages; ++i) {
+      const ips_page_scan& pg = h_pages[i];
+      if (pg.n_rows == 0) continue;
+      st = scan_common(pg.d_enc, pg.n_rows, bit_width, args, kind, pg.d_bitmap, pg.d_batch_values,
+                       pg.d_batch_counts, 0, nullptr, 0, nullptr, s);
+      if (st != IPS_OK) return st;
+    }
+    return IPS_OK;
+  }
+  for (int first = 0; first < n_pages; first += kPagesPerLaunch) {
+    PageBatch batch;
+    memset(&batch, 0, sizeof(batch));
+    int n = 0;
+    int64_t max_rows = 0;
+    for (int i = first; i < n_pages && i < first + kPagesPerLaunch; ++i) {
+      const ips_page_scan& pg = h_pages[i];
+      if (pg.n_rows == 0) continue;
+      batch.pages[n++] = PageScan{reinterpret_cast<const uint64_t*>(pg.d_enc), pg.n_rows,
+                                  reinterpret_cast<uint32_t*>(pg.d_bitmap), pg.d_batch_values,
+                                  pg.d_batch_counts};
+      if (pg.n_rows > max_rows) max_rows = pg.n_rows;
+    }
+    if (n == 0) continue;
+    if (bit_width <= 8) st = launch_fle_scan_pages_part_a(bit_width, batch, n, max_rows, args, s);
+    else if (bit_width <= 16) st = launch_fle_scan_pages_part_b(bit_width, batch, n, max_rows, args, s);
+    else if (bit_width <= 24) st = launch_fle_scan_pages_part_c(bit_width, batch, n, max_rows, args, s);
+    else st = launch_fle_scan_pages_part_d(bit_width, batch, n, max_rows, args, s);
+    if (st != IPS_OK) return st;
+  }
+  return IPS_OK;
 }
 
 size_t ips_batches_workspace_bytes(int64_t n_rows) { return batches_workspace_bytes(n_batches_of(n_rows)); }

@@ -65,13 +65,14 @@ __device__ __forceinline__ uint32_t in_table_lookup(const uint32_t* table, const
 // Replaces EvalSimplePredicates + bitmap->skip-list + ReadValue(skip) of one column
 // (hdfs-parquet-scanner.cc:1837-1865, 1134-1181, 1006-1027; fle-encoding.h:8012-8066, 344-379).
 // ---------------------------------------------------------------------------------------------
+// first_tile / stride: the sub-tiles this wave takes (tile = first_tile, first_tile + stride, ...)
 template <int W, int MODE, int G>
-__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kernel(
-    const uint64_t* __restrict__ enc, int64_t n_rows, PredArgs args,
+__device__ __forceinline__ void fle_scan_body(
+    const uint64_t* __restrict__ enc, int64_t n_rows, const PredArgs& args,
     uint32_t* __restrict__ bitmap32, const uint32_t* __restrict__ given_bitmap32,
     typename GatherT<G>::type* __restrict__ batch_values, uint32_t* __restrict__ batch_counts,
     const typename GatherT<G>::type* __restrict__ dict, uint32_t dict_entries,
-    int32_t* __restrict__ bad_index) {
+    int32_t* __restrict__ bad_index, int64_t first_tile, int64_t stride) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kRowTileBytes / 4];
   using GT = typename GatherT<G>::type;
   __shared__ GT dict_lds[DictLds<W, G>::kEntries];
@@ -94,9 +95,8 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kerne
 
   const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   const int64_t total_words = ((n_rows + 63) / 64) * W;
-  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
   const int64_t bm_dwords = bitmap_dwords(n_rows);
-  int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  int64_t tile = first_tile;
 
   u32x4 r[L];
   if (tile < tiles) tile_load<L>(enc, tile, W, total_words, lane, r);
@@ -196,6 +196,52 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kerne
     wave_lds_fence();  // LDS region is reused by the next sub-tile
     tile = next;
   }
+}
+
+template <int W, int MODE, int G>
+__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kernel(
+    const uint64_t* __restrict__ enc, int64_t n_rows, PredArgs args,
+    uint32_t* __restrict__ bitmap32, const uint32_t* __restrict__ given_bitmap32,
+    typename GatherT<G>::type* __restrict__ batch_values, uint32_t* __restrict__ batch_counts,
+    const typename GatherT<G>::type* __restrict__ dict, uint32_t dict_entries,
+    int32_t* __restrict__ bad_index) {
+  fle_scan_body<W, MODE, G>(enc, n_rows, args, bitmap32, given_bitmap32, batch_values, batch_counts,
+                            dict, dict_entries, bad_index,
+                            (int64_t)blockIdx.x * kWavesPerBlock + wave_id(),
+                            (int64_t)gridDim.x * kWavesPerBlock);
+}
+
+// Many data pages (separate buffers) in ONE launch: blockIdx.y picks the page, blockIdx.x the
+// share of its sub-tiles.  A scanner holds a column chunk as a list of pages (ReadDataPage /
+// InitDataPage per page, hdfs-parquet-scanner.cc:882-916; row groups and pages are independent,
+// :1056-1060): a 2^20-row page is 0.8 us of HBM time, far below a launch.
+struct PageScan {
+  const uint64_t* enc;
+  int64_t n_rows;
+  uint32_t* bitmap32;
+  uint32_t* batch_values;
+  uint32_t* batch_counts;
+};
+constexpr int kPagesPerLaunch = 64;  // 64 descriptors + PredArgs stay below the 4 KiB kernarg limit
+struct PageBatch { PageScan pages[kPagesPerLaunch]; };
+
+// The descriptors travel in the kernel argument itself (no page table in device memory, nothing to
+// copy or synchronise, capturable in a hipGraph); the page's row is read through the
+// constant-address-space kernarg pointer -- indexing the by-value argument with blockIdx.y would
+// make the compiler copy all of it to scratch.
+template <int W>
+__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_pages_kernel(
+    PageBatch batch, PredArgs args) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)batch;
+  typedef __attribute__((address_space(4))) const PageScan* KargPages;
+  KargPages pages = (KargPages)__builtin_amdgcn_kernarg_segment_ptr();  // 'batch' is argument 0
+  const PageScan pg = pages[blockIdx.y];
+  fle_scan_body<W, kScanPredicate, 0>(pg.enc, pg.n_rows, args, pg.bitmap32, nullptr,
+                                      pg.batch_values, pg.batch_counts, nullptr, 0u, nullptr,
+                                      (int64_t)blockIdx.x * kWavesPerBlock + wave_id(),
+                                      (int64_t)gridDim.x * kWavesPerBlock);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -85,6 +85,35 @@ ips_status IPS_CAT(launch_fle_scan_part_, IPS_PART)(
   return IPS_ERR_INVALID_ARG;
 }
 
+template <int W>
+static ips_status launch_pages_w(const PageBatch& batch, int n_pages, int64_t max_rows,
+                                 const PredArgs& args, hipStream_t s) {
+  auto kern = fle_scan_pages_kernel<W>;
+  const int64_t tiles = (max_rows + kRowsPerTile - 1) / kRowsPerTile;  // of the largest page
+  // x: shares of one page's sub-tiles, so that x * n_pages fills the device about grid_mult() times
+  const int total = grid_for_tiles(reinterpret_cast<const void*>(kern), tiles * (int64_t)n_pages);
+  int64_t gx = (total + n_pages - 1) / n_pages;
+  const int64_t gx_max = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (gx > gx_max) gx = gx_max;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)n_pages), dim3(kThreads), 0, s, batch, args);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+ips_status IPS_CAT(launch_fle_scan_pages_part_, IPS_PART)(int w, const PageBatch& batch,
+                                                          int n_pages, int64_t max_rows,
+                                                          const PredArgs& args, hipStream_t s) {
+#define IPS_CASE(N) \
+  case IPS_WLO + N: return launch_pages_w<IPS_WLO + N>(batch, n_pages, max_rows, args, s);
+  switch (w) {
+    IPS_CASE(0) IPS_CASE(1) IPS_CASE(2) IPS_CASE(3) IPS_CASE(4) IPS_CASE(5) IPS_CASE(6) IPS_CASE(7)
+  }
+#undef IPS_CASE
+  set_error("bit width %d outside part starting at %d", w, IPS_WLO);
+  return IPS_ERR_INVALID_ARG;
+}
+
 template <int W, int KIND>
 static ips_status launch_pred_wk(const uint64_t* enc, int64_t n_rows, const PredArgs& args,
                                  uint32_t* bitmap32, hipStream_t s) {

@@ -125,6 +125,22 @@ ips_status ips_fle_scan(const void* d_enc, int64_t n_rows, int bit_width, ips_op
                         const uint64_t* consts, int n_consts, uint64_t* d_bitmap,
                         uint32_t* d_batch_values, uint32_t* d_batch_counts, ips_stream stream);
 
+/* ips_fle_scan over MANY data pages (separate buffers) with one launch per 64 pages: the scanner
+ * holds a column chunk as a list of pages (ReadDataPage / InitDataPage per page,
+ * hdfs-parquet-scanner.cc:882-916; pages and row groups are independent, :1056-1060), and a
+ * 2^20-row page is 0.8 us of HBM time -- far below a launch.  Every page has its own outputs,
+ * laid out as ips_fle_scan lays them out; all pages share bit_width and the predicate (EQ..GE).
+ * The page descriptors travel in the kernel argument: no device-side table, no copy, capturable. */
+typedef struct {
+  const void* d_enc;        /* FLE blocks of the page, 16-byte aligned */
+  int64_t n_rows;
+  uint64_t* d_bitmap;       /* ceil(n_rows/64) words */
+  uint32_t* d_batch_values; /* ceil(n_rows/IPS_BATCH_ROWS) batches of IPS_BATCH_ROWS slots */
+  uint32_t* d_batch_counts; /* ceil(n_rows/IPS_BATCH_ROWS) counts */
+} ips_page_scan;
+ips_status ips_fle_scan_pages(const ips_page_scan* h_pages, int n_pages, int bit_width, ips_op op,
+                              const uint64_t* consts, int n_consts, ips_stream stream);
+
 /* Late materialisation against an existing bitmap (e.g. the AND of several columns' predicates):
  * per batch, the values of the rows whose bitmap bit is set (ReadValue(skip) per selected row,
  * hdfs-parquet-scanner.cc:1151-1181).  Same output layout as ips_fle_scan. */

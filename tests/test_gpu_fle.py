@@ -173,3 +173,35 @@ def test_reference_padding_is_ignored(capi, O):
         b = words(capi.fle_pred(enc_to_dev(dirty), n, bw, op, 100))
         assert np.array_equal(a, b)
     assert np.array_equal(capi.fle_decode(enc_to_dev(dirty), n, bw).cpu().numpy().view(np.uint32), vals)
+
+
+@pytest.mark.parametrize("bw", [1, 7, 12, 16, 21, 32])
+def test_scan_pages_equals_per_page_scan(capi, O, bw):
+    """ips_fle_scan_pages over separate page buffers of ragged sizes (empty, one row, below and
+    above one batch, above the 64-page launch group) equals ips_fle_scan page by page and the
+    oracle."""
+    rng = np.random.default_rng(1200 + bw)
+    sizes = [0, 1, 63, 2048, 2049, 5000, 70001] + [int(x) for x in rng.integers(1, 9000, 70)]
+    pages, refs = [], []
+    for n in sizes:
+        vals = rand_vals(rng, max(n, 1), bw)[:n]
+        ref_enc = O.fle_encode(vals, bw) if n else np.zeros(0, np.uint64)
+        enc = enc_to_dev(ref_enc) if n else torch.zeros(2, dtype=torch.int64, device="cuda")
+        outs = capi.alloc_scan_outputs(n, torch.device("cuda"))
+        pages.append((enc, n, outs))
+        refs.append((ref_enc, vals))
+    plist = capi.make_page_list(pages)
+    for op, c in ((O.OP_LT, (1 << bw) // 10 + 1), (O.OP_GE, (1 << bw) // 2), (O.OP_EQ, int(refs[5][1][0])),
+                  (O.OP_LE, (1 << bw) - 1), (O.OP_GT, (1 << bw) - 1)):
+        for _, _, outs in pages:
+            for t in outs:
+                t.fill_(-1)
+        capi.fle_scan_pages(plist, bw, op, c)
+        for (enc, n, outs), (ref_enc, vals) in zip(pages, refs):
+            if n == 0:
+                continue
+            bm_ref = O.fle_pred(ref_enc, n, bw, op, c)
+            assert np.array_equal(words(outs[0][:(n + 63) // 64]), bm_ref), (bw, n, op)
+            check_batches(outs[1], outs[2][:(n + 2047) // 2048], n, O.fle_select(ref_enc, n, bw, bm_ref), capi)
+    with pytest.raises(capi.IpsError):
+        capi.fle_scan_pages(plist, bw, O.OP_IN, [0, 1])
