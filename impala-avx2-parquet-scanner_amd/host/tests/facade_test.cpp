@@ -40,7 +40,7 @@ static void ValidateFle(const std::vector<int>& values, int bit_width, int expec
   if (expected_len != -1) CHECK(encoded_len == expected_len);
   FleDecoder decoder(buffer.data(), encoded_len, bit_width);
   for (size_t i = 0; i < values.size(); ++i) {
-    uint64_t val;
+    uint64_t val = 0;
     bool result = decoder.Get(&val);
     CHECK(result);
     CHECK((uint64_t)values[i] == val);
@@ -312,7 +312,7 @@ static void TestScanner() {
       int64_t r = row;
       for (int skip : skip_rows) {
         r += skip;
-        int32_t v0; int64_t v1; int32_t v2;
+        int32_t v0 = 0; int64_t v1 = 0; int32_t v2 = 0;
         CHECK(scanner.ReadValue(0, &v0, skip) && v0 == c0[r]);
         CHECK(scanner.ReadValue(1, &v1, skip) && v1 == c1[r]);
         CHECK(scanner.ReadValue(2, &v2, skip) && v2 == c2[r]);
