@@ -412,3 +412,63 @@ def test_dict_encode_on_gpu(capi, O, type_name):
         big = torch.arange(0, 50000, dtype=torch.int32, device="cuda")
         with pytest.raises(capi.IpsError):
             capi.dict_encode(big, t)
+
+
+@pytest.mark.parametrize("strategy", ["auto", "general"])
+def test_random_predicate_trees(capi, O, strategy, monkeypatch):
+    """Random AND/OR trees (up to 12 leaves, any shape) over FLE and PLAIN columns against numpy:
+    exercises the per-operand planner's bitmap stack (which bitmap ends up as the root, temporaries,
+    same-column pairs, IN leaves) and the one-launch interpreter on the same programs."""
+    if strategy == "general":
+        monkeypatch.setenv("IPS_PROGRAM_NO_CHAIN", "1")
+    else:
+        monkeypatch.delenv("IPS_PROGRAM_NO_CHAIN", raising=False)
+    rng = np.random.default_rng(4242)
+    n = 20000 + 37
+    widths = (5, 12, 20)
+    fle_np = [rng.integers(0, 1 << w, n).astype(np.uint32) for w in widths]
+    p32 = rng.integers(-100, 100, n).astype(np.int32)
+    p64 = rng.integers(-10 ** 6, 10 ** 6, n).astype(np.int64)
+    encs = [dev_words(O.fle_encode(v, w)) for v, w in zip(fle_np, widths)]
+    pad = np.zeros(16, np.uint8)
+    d32 = torch.from_numpy(np.concatenate([p32.view(np.uint8), pad])).cuda()
+    d64 = torch.from_numpy(np.concatenate([p64.view(np.uint8), pad])).cuda()
+    cols = [capi.fle_column(e, w) for e, w in zip(encs, widths)] + \
+           [capi.plain_column(d32, O.T_INT32), capi.plain_column(d64, O.T_INT64)]
+    data = fle_np + [p32, p64]
+    ops = {O.OP_EQ: np.equal, O.OP_LT: np.less, O.OP_LE: np.less_equal, O.OP_GT: np.greater,
+           O.OP_GE: np.greater_equal}
+
+    def random_leaf():
+        col = int(rng.integers(0, 5))
+        x = data[col]
+        if col < 3 and rng.random() < 0.25:
+            lst = [int(v) for v in rng.choice(x, int(rng.integers(1, 13)))]
+            return capi.leaf(col, O.OP_IN, lst), np.isin(x, lst)
+        op = int(rng.choice(list(ops)))
+        lit = x[int(rng.integers(0, n))]
+        if col < 3:
+            return capi.leaf(col, op, int(lit)), ops[op](x, lit)
+        t = O.T_INT32 if col == 3 else O.T_INT64
+        return capi.plain_leaf(col, op, lit, t), ops[op](x, lit)
+
+    def random_tree(leaves):
+        """-> (postfix nodes, numpy truth, stack depth needed)"""
+        if leaves == 1:
+            nd, truth = random_leaf()
+            return [nd], truth, 1
+        left = int(rng.integers(1, leaves))
+        a, ta, da = random_tree(left)
+        b, tb, db = random_tree(leaves - left)
+        if rng.random() < 0.5:
+            return a + b + [capi.and_node()], ta & tb, max(da, db + 1)
+        return a + b + [capi.or_node()], ta | tb, max(da, db + 1)
+
+    done = 0
+    while done < 25:
+        nodes, truth, depth = random_tree(int(rng.integers(1, 13)))
+        if depth > 8:            # the interpreter's stack (both strategies accept <= 8)
+            continue
+        got = bits_of(words(capi.eval_program(nodes, cols, n)), n)
+        assert np.array_equal(got, truth), (strategy, done, len(nodes))
+        done += 1
