@@ -472,3 +472,56 @@ def test_random_predicate_trees(capi, O, strategy, monkeypatch):
         got = bits_of(words(capi.eval_program(nodes, cols, n)), n)
         assert np.array_equal(got, truth), (strategy, done, len(nodes))
         done += 1
+
+
+def test_entry_points_capture_into_a_graph(capi, O):
+    """The launch-only entry points neither allocate nor synchronise, so a host can capture a
+    page's whole evaluation into a hipGraph and replay it (bench.py does so for the 2^20-row
+    latency figure): predicate, fused scan, the page-list scan and ips_eval_program -- including
+    a tree that needs a temporary bitmap -- captured once, replayed on new data."""
+    rng = np.random.default_rng(77)
+    n = 50000
+    a = rng.integers(0, 1 << 12, n).astype(np.uint32)
+    b = rng.integers(0, 1 << 6, n).astype(np.uint32)
+    ea, eb = dev_words(O.fle_encode(a, 12)), dev_words(O.fle_encode(b, 6))
+    outs = capi.alloc_scan_outputs(n, torch.device("cuda"))
+    bm_pred = torch.zeros((n + 63) // 64 + 2, dtype=torch.int64, device="cuda")
+    bm_chain = torch.zeros_like(bm_pred)
+    bm_tree = torch.zeros_like(bm_pred)
+    cols = [capi.fle_column(ea, 12), capi.fle_column(eb, 6)]
+    L, AND, OR = capi.leaf, capi.and_node, capi.or_node
+    chain = [L(0, O.OP_GE, 100), L(0, O.OP_LT, 3000), AND(), L(1, O.OP_LT, 40), AND()]
+    tree = [L(0, O.OP_LT, 500), L(1, O.OP_GE, 10), AND(), L(0, O.OP_GE, 3500), L(1, O.OP_LT, 5), AND(), OR()]
+    pages = [(ea, n, capi.alloc_scan_outputs(n, torch.device("cuda")))]
+    plist = capi.make_page_list(pages)
+
+    def work():
+        capi.fle_pred(ea, n, 12, O.OP_LT, 1000, bitmap=bm_pred)
+        capi.fle_scan(ea, n, 12, O.OP_LT, 1000, outputs=outs)
+        capi.fle_scan_pages(plist, 12, O.OP_GE, 2000)
+        capi.eval_program(chain, cols, n, bitmap=bm_chain)
+        capi.eval_program(tree, cols, n, bitmap=bm_tree)
+
+    work()                                   # warm-up outside the capture (module loading etc.)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            work()
+    torch.cuda.current_stream().wait_stream(side)
+    # new data in the same buffers, then replay
+    a2 = rng.integers(0, 1 << 12, n).astype(np.uint32)
+    ea.copy_(dev_words(O.fle_encode(a2, 12)))
+    for t in (bm_pred, bm_chain, bm_tree, outs[0], pages[0][2][0]):
+        t.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    W = (n + 63) // 64
+    assert np.array_equal(bits_of(words(bm_pred[:W]), n), a2 < 1000)
+    assert np.array_equal(bits_of(words(outs[0][:W]), n), a2 < 1000)
+    assert np.array_equal(bits_of(words(pages[0][2][0][:W]), n), a2 >= 2000)
+    assert np.array_equal(bits_of(words(bm_chain[:W]), n), (a2 >= 100) & (a2 < 3000) & (b < 40))
+    assert np.array_equal(bits_of(words(bm_tree[:W]), n),
+                          ((a2 < 500) & (b >= 10)) | ((a2 >= 3500) & (b < 5)))
