@@ -100,22 +100,20 @@ static ips_status dict_encode_t(const void* d_values, int64_t n, ips_type type, 
   uint32_t* d_code_of_slot = nullptr;
   uint32_t* d_codes = nullptr;
   auto cleanup = [&]() {
-    // stream-ordered pool: no device-wide synchronisation, and the 4n-byte code buffer of the next
-    // chunk comes out of the pool instead of the driver
-    if (d_table) (void)hipFreeAsync(d_table, s);
-    if (d_counters) (void)hipFreeAsync(d_counters, s);
-    if (d_code_of_slot) (void)hipFreeAsync(d_code_of_slot, s);
-    if (d_codes) (void)hipFreeAsync(d_codes, s);
+    if (d_table) (void)hipFree(d_table);
+    if (d_counters) (void)hipFree(d_counters);
+    if (d_code_of_slot) (void)hipFree(d_code_of_slot);
+    if (d_codes) (void)hipFree(d_codes);
   };
 #define IPS_TRY_CLEAN(expr)                                     \
   do {                                                          \
     hipError_t _e = (expr);                                     \
     if (_e != hipSuccess) { cleanup(); return hip_fail(_e, #expr); } \
   } while (0)
-  IPS_TRY_CLEAN(hipMallocAsync(reinterpret_cast<void**>(&d_table), (size_t)kTableSlots * 8, s));
-  IPS_TRY_CLEAN(hipMallocAsync(reinterpret_cast<void**>(&d_counters), 8, s));
-  IPS_TRY_CLEAN(hipMallocAsync(reinterpret_cast<void**>(&d_code_of_slot), (size_t)kTableSlots * 4, s));
-  IPS_TRY_CLEAN(hipMallocAsync(reinterpret_cast<void**>(&d_codes), (size_t)(n > 0 ? n : 1) * 4 + 16, s));
+  IPS_TRY_CLEAN(hipMalloc(&d_table, (size_t)kTableSlots * 8));
+  IPS_TRY_CLEAN(hipMalloc(&d_counters, 8));
+  IPS_TRY_CLEAN(hipMalloc(&d_code_of_slot, (size_t)kTableSlots * 4));
+  IPS_TRY_CLEAN(hipMalloc(&d_codes, (size_t)(n > 0 ? n : 1) * 4 + 16));
   IPS_TRY_CLEAN(hipMemsetAsync(d_table, 0xFF, (size_t)kTableSlots * 8, s));
   IPS_TRY_CLEAN(hipMemsetAsync(d_counters, 0, 8, s));
   const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_cus() * 8);

@@ -353,6 +353,47 @@ static void TestScanner() {
   CHECK(unknown_fn.CreateSimplePredicates(&s) == NULL);
 }
 
+// ips_eval_program straight through the C-ABI from a plain C++ process: an OR of two conjunctions
+// needs a temporary bitmap next to d_bitmap (stream-ordered allocation inside the call).
+static void TestProgramWithTemporaryBitmap() {
+  const int n = 70001;
+  std::vector<uint32_t> a(n), b(n);
+  for (int i = 0; i < n; ++i) { a[i] = (uint32_t)(rnd() % 4096); b[i] = (uint32_t)(rnd() % 64); }
+  ips::DeviceBuffer da, db, ea((size_t)ips_fle_encoded_bytes(n, 12)), eb((size_t)ips_fle_encoded_bytes(n, 6));
+  CHECK(da.upload(a.data(), (size_t)n * 4) && db.upload(b.data(), (size_t)n * 4));
+  CHECK(ips_fle_encode(da.get(), 4, n, 12, ea.get(), nullptr) == IPS_OK);
+  CHECK(ips_fle_encode(db.get(), 4, n, 6, eb.get(), nullptr) == IPS_OK);
+  ips_column cols[2] = {{IPS_COL_FLE, 12, 0, 0, ea.get()}, {IPS_COL_FLE, 6, 0, 0, eb.get()}};
+  auto leaf = [](int col, ips_op op, uint64_t c) {
+    ips_node nd;
+    memset(&nd, 0, sizeof(nd));
+    nd.kind = IPS_NODE_LEAF; nd.column = col; nd.op = op; nd.n_consts = 1; nd.consts[0] = c;
+    return nd;
+  };
+  auto inner = [](ips_node_kind k) { ips_node nd; memset(&nd, 0, sizeof(nd)); nd.kind = k; return nd; };
+  // (a < 500 AND b >= 10) OR (a >= 3500 AND b < 5) OR (b == 63 AND a IN-range via two leaves)
+  ips_node prog[] = {leaf(0, IPS_OP_LT, 500), leaf(1, IPS_OP_GE, 10), inner(IPS_NODE_AND),
+                     leaf(0, IPS_OP_GE, 3500), leaf(1, IPS_OP_LT, 5), inner(IPS_NODE_AND),
+                     inner(IPS_NODE_OR),
+                     leaf(1, IPS_OP_EQ, 63), leaf(0, IPS_OP_GE, 1000), leaf(0, IPS_OP_LE, 2000),
+                     inner(IPS_NODE_AND), inner(IPS_NODE_AND), inner(IPS_NODE_OR)};
+  const int64_t words = (n + 63) / 64;
+  ips::DeviceBuffer bm((size_t)words * 8);
+  for (int rep = 0; rep < 3; ++rep) {
+    CHECK(ips_eval_program(prog, (int)(sizeof(prog) / sizeof(prog[0])), cols, 2, n,
+                           bm.as<uint64_t>(), nullptr) == IPS_OK);
+    std::vector<uint64_t> h((size_t)words);
+    CHECK(bm.download(h.data(), (size_t)words * 8));
+    int bad = 0;
+    for (int i = 0; i < n; ++i) {
+      const bool e = (a[i] < 500 && b[i] >= 10) || (a[i] >= 3500 && b[i] < 5) ||
+                     (b[i] == 63 && a[i] >= 1000 && a[i] <= 2000);
+      if ((((h[(size_t)i >> 6]) >> (i & 63)) & 1ull) != (uint64_t)e) ++bad;
+    }
+    CHECK(bad == 0);
+  }
+}
+
 int main() {
   int count = 0;
   if (ips_device_count(&count) != IPS_OK || count == 0) {
@@ -367,6 +408,7 @@ int main() {
   TestDictPredicates<int32_t>(); TestDictPredicates<int64_t>(); TestDictPredicates<double>();
   TestDictPredicates<int16_t>(); TestDictPredicates<float>();
   TestScanner();
+  TestProgramWithTemporaryBitmap();
   CHECK(ips::sticky_status() == IPS_OK);
   printf("facade_test: %d checks, %d failed\n", g_checks, g_fail);
   return g_fail ? 1 : 0;
