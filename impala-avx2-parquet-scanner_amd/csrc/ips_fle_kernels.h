@@ -22,11 +22,13 @@ struct GatherT<8> { using type = uint64_t; };
 // copied into LDS once per workgroup and the gather reads it there: a dependent global load per
 // selected value is what bounded the narrow dictionary scans (w=8 IN scan + gather 107 -> 87 us).
 // At 16 KiB (w=12) the per-workgroup copy and the lost occupancy cost more than they save.
-template <int W, int G>
+// The full decode gathers EVERY row, so there the copy pays up to 32 KiB (w=12: 476 -> 2xx us).
+template <int W, int G, int MAX_BYTES = 4096>
 struct DictLds {
-  static constexpr bool kUse = G != 0 && W <= 12 && ((1 << (W <= 12 ? W : 0)) * G) <= 4096;
-  static constexpr int kEntries = kUse ? (1 << (W <= 12 ? W : 0)) : 1;
+  static constexpr bool kUse = G != 0 && W <= 13 && ((1 << (W <= 13 ? W : 0)) * G) <= MAX_BYTES;
+  static constexpr int kEntries = kUse ? (1 << (W <= 13 ? W : 0)) : 1;
 };
+constexpr int kDecodeDictLdsBytes = 32768;
 
 // Long IN lists on narrow columns (every dictionary code width): membership becomes a 2^W-bit set
 // in LDS, built once per workgroup, and each decoded value costs one LDS read -- independent of
@@ -325,18 +327,18 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_decode_ker
     int32_t* __restrict__ bad_index) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kRowTileBytes / 4];
   using GT = typename GatherT<G>::type;
-  __shared__ GT dict_lds[DictLds<W, G>::kEntries];
+  __shared__ GT dict_lds[DictLds<W, G, kDecodeDictLdsBytes>::kEntries];
   constexpr int L = (16 * W + kWave - 1) / kWave;
   const int lane = lane_id();
   const int wave = wave_id();
   uint32_t* lds32 = lds_all + wave * (kRowTileBytes / 4);
-  if constexpr (DictLds<W, G>::kUse) {
-    for (uint32_t i = threadIdx.x; i < dict_entries && i < (uint32_t)DictLds<W, G>::kEntries; i += kThreads)
+  if constexpr (DictLds<W, G, kDecodeDictLdsBytes>::kUse) {
+    for (uint32_t i = threadIdx.x; i < dict_entries && i < (uint32_t)DictLds<W, G, kDecodeDictLdsBytes>::kEntries; i += kThreads)
       dict_lds[i] = dict[i];
     __syncthreads();
   }
   auto lookup = [&](uint32_t code) -> GT {
-    if constexpr (DictLds<W, G>::kUse) return dict_lds[code];
+    if constexpr (DictLds<W, G, kDecodeDictLdsBytes>::kUse) return dict_lds[code];
     else return dict[code];
   };
 

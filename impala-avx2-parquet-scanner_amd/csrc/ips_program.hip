@@ -8,6 +8,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "ips_host.h"
 
 namespace ips {
@@ -404,8 +408,37 @@ ips_status emit_item(const ChainItem& it, int combine, const ips_column* cols, i
 // Plans the whole tree on a stack of bitmaps.  Operands are folded into an existing bitmap
 // whenever one side of an AND / OR already is one (both commute); two leaf operands open a new
 // bitmap; two bitmaps are merged by ips_bitmap_and / or's kernel.  The bitmap the root ends up in
-// is mapped onto d_bitmap, the others (a left-deep conjunct chain has none) live in one
-// stream-ordered temporary allocation.
+// is mapped onto d_bitmap, the others (a left-deep conjunct chain has none) live in the stream's
+// scratch buffer (plan_scratch).
+// Temporary bitmaps of a plan: one grow-only buffer per (device, stream), plain hipMalloc memory
+// like every other buffer the kernels touch.  Work on a stream is ordered, so consecutive calls
+// on one stream may share it; growing it frees the old one with hipFree, which waits for the
+// device first.  (The stream-ordered allocator was tried: its pool memory aborted a torch-free
+// host process in ips_dict_encode and is kept out of the product path.)  The first call that
+// needs temporaries on a stream therefore allocates; while that stream is being captured into a
+// hipGraph no allocation is allowed, *out stays NULL and the caller takes the one-launch kernel.
+ips_status plan_scratch(hipStream_t s, size_t bytes, uint8_t** out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, std::pair<void*, size_t>> cache;
+  int dev = 0;
+  IPS_HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto& e = cache[std::make_pair(dev, s)];
+  *out = nullptr;
+  if (e.second < bytes) {
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone)
+      return IPS_OK;
+    if (e.first) IPS_HIP_TRY(hipFree(e.first));
+    e.first = nullptr;
+    e.second = 0;
+    IPS_HIP_TRY(hipMalloc(&e.first, bytes));
+    e.second = bytes;
+  }
+  *out = reinterpret_cast<uint8_t*>(e.first);
+  return IPS_OK;
+}
+
 // returns IPS_OK and *handled = true when the plan has been launched
 ips_status try_chain(const ips_node* nodes, int n_nodes, const ips_column* cols, int64_t n_rows,
                      uint64_t* d_bitmap, hipStream_t s, bool* handled) {
@@ -451,7 +484,11 @@ ips_status try_chain(const ips_node* nodes, int n_nodes, const ips_column* cols,
   const size_t bitmap_bytes = (size_t)((n_rows + 63) / 64) * 8;
   const size_t slot_bytes = (bitmap_bytes + 255) & ~(size_t)255;
   uint8_t* temp = nullptr;
-  if (n_slots > 1) IPS_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&temp), slot_bytes * (size_t)(n_slots - 1), s));
+  if (n_slots > 1) {
+    ips_status sst = plan_scratch(s, slot_bytes * (size_t)(n_slots - 1), &temp);
+    if (sst != IPS_OK) return sst;
+    if (!temp) return IPS_OK;  // capturing without scratch: not handled here
+  }
   auto slot_ptr = [&](int slot) -> uint64_t* {
     if (slot == root) return d_bitmap;
     return reinterpret_cast<uint64_t*>(temp + slot_bytes * (size_t)(slot < root ? slot : slot - 1));
@@ -461,10 +498,6 @@ ips_status try_chain(const ips_node* nodes, int n_nodes, const ips_column* cols,
     const Step& p = plan[i];
     if (p.kind == 0) st = emit_item(ChainItem{false, p.item.a, p.item.b, p.item.join}, p.combine, cols, n_rows, slot_ptr(p.dst), s);
     else st = launch_bitmap_binop(p.combine == 1 ? 0 : 1, slot_ptr(p.dst), slot_ptr(p.src), (n_rows + 63) / 64, s);
-  }
-  if (temp) {
-    hipError_t e = hipFreeAsync(temp, s);
-    if (st == IPS_OK && e != hipSuccess) st = hip_fail(e, "hipFreeAsync");
   }
   if (st != IPS_OK) return st;
   *handled = true;

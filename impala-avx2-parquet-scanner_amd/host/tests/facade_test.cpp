@@ -384,12 +384,17 @@ static void TestProgramWithTemporaryBitmap() {
                            bm.as<uint64_t>(), nullptr) == IPS_OK);
     std::vector<uint64_t> h((size_t)words);
     CHECK(bm.download(h.data(), (size_t)words * 8));
-    int bad = 0;
+    int bad = 0, first_bad = -1;
     for (int i = 0; i < n; ++i) {
       const bool e = (a[i] < 500 && b[i] >= 10) || (a[i] >= 3500 && b[i] < 5) ||
                      (b[i] == 63 && a[i] >= 1000 && a[i] <= 2000);
-      if ((((h[(size_t)i >> 6]) >> (i & 63)) & 1ull) != (uint64_t)e) ++bad;
+      if ((((h[(size_t)i >> 6]) >> (i & 63)) & 1ull) != (uint64_t)e) {
+        if (first_bad < 0) first_bad = i;
+        ++bad;
+      }
     }
+    if (bad) fprintf(stderr, "program with temporary bitmap: rep %d: %d wrong bits, first at row %d (a=%u b=%u)\n",
+                     rep, bad, first_bad, a[(size_t)first_bad], b[(size_t)first_bad]);
     CHECK(bad == 0);
   }
 }

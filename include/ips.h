@@ -301,7 +301,11 @@ typedef struct {
   int32_t column;        /* leaf: index into cols */
   int32_t op;            /* leaf: ips_op (FLE: on codes/values; PLAIN: SQL semantics) */
   int32_t n_consts;      /* leaf: 1, or 1..16 for IN */
-  uint64_t consts[16];   /* leaf: FLE constants, or PLAIN literal bit patterns */
+  uint64_t consts[16];   /* leaf: FLE constants, or PLAIN literal bit patterns 
+ * Trees that keep more than one bitmap alive (an OR of ANDs) use a scratch buffer the library keeps
+ * per (device, stream); the first such call on a stream allocates it.  While the stream is being
+ * captured into a hipGraph and no scratch exists yet, the one-launch interpreter kernel is used
+ * instead (same result, no allocation). */
 } ips_node;
 
 #define IPS_PROGRAM_MAX_NODES 32
