@@ -301,15 +301,15 @@ typedef struct {
   int32_t column;        /* leaf: index into cols */
   int32_t op;            /* leaf: ips_op (FLE: on codes/values; PLAIN: SQL semantics) */
   int32_t n_consts;      /* leaf: 1, or 1..16 for IN */
-  uint64_t consts[16];   /* leaf: FLE constants, or PLAIN literal bit patterns 
- * Trees that keep more than one bitmap alive (an OR of ANDs) use a scratch buffer the library keeps
- * per (device, stream); the first such call on a stream allocates it.  While the stream is being
- * captured into a hipGraph and no scratch exists yet, the one-launch interpreter kernel is used
- * instead (same result, no allocation). */
+  uint64_t consts[16];   /* leaf: FLE constants, or PLAIN literal bit patterns */
 } ips_node;
 
 #define IPS_PROGRAM_MAX_NODES 32
 #define IPS_PROGRAM_MAX_COLS 8
+/* Trees that keep more than one bitmap alive (an OR of ANDs) use a scratch buffer the library keeps
+ * per (device, stream); the first such call on a stream allocates it.  While the stream is being
+ * captured into a hipGraph and no scratch exists yet, the one-launch interpreter kernel is used
+ * instead (same result, no allocation). */
 ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const ips_column* cols, int n_cols,
                             int64_t n_rows, uint64_t* d_bitmap, ips_stream stream);
 
