@@ -720,6 +720,19 @@ ips_status ips_plain_pred(const void* d_page, int64_t n_rows, ips_type type, ips
   return launch_plain_pred(type, d_page, n_rows, eff, literals, n_literals, d_bitmap, S(stream));
 }
 
+ips_status ips_plain_select(const void* d_page, int64_t n_rows, ips_type type,
+                            const uint64_t* d_bitmap, void* d_batch_values,
+                            uint32_t* d_batch_counts, ips_stream stream) {
+  IPS_REQUIRE(valid_type(type), "ips_plain_select: bad type %d", (int)type);
+  IPS_REQUIRE(n_rows >= 0, "ips_plain_select: n_rows < 0");
+  IPS_REQUIRE(n_rows == 0 || (d_page && aligned16(d_page) && d_bitmap && aligned16(d_bitmap) &&
+                              d_batch_values && aligned16(d_batch_values) && d_batch_counts),
+              "ips_plain_select: NULL or misaligned argument");
+  if (n_rows == 0) return IPS_OK;
+  return launch_plain_select(ips_plain_stride(type), d_page, n_rows, d_bitmap, d_batch_values,
+                             d_batch_counts, S(stream));
+}
+
 // ---- bitmap algebra -------------------------------------------------------------------------
 ips_status ips_bitmap_and(uint64_t* d_a, const uint64_t* d_b, int64_t n_rows, ips_stream stream) {
   IPS_REQUIRE(n_rows >= 0 && (n_rows == 0 || (d_a && d_b)), "ips_bitmap_and: bad argument");

@@ -169,6 +169,75 @@ ips_status launch_plain_pred(int type, const void* page, int64_t n_rows, int op,
 }
 
 // =============================================================================================
+// Late materialisation on a PLAIN page: ReadValue(skip) -> ParquetPlainEncoder::Decode(buffer,
+// size, &val, skip_rows) per selected row (parquet-common.h:186-190, hdfs-parquet-scanner.cc:
+// 1006-1027).  One wave per 2048-row batch: lane l owns rows 32l..32l+31 of the batch (one bitmap
+// dword), a DPP prefix sum of the popcounts gives its first output slot, then it walks its set
+// bits four at a time -- four independent slot loads in flight -- and stores them in row order.
+// Same batch layout as ips_fle_select.
+// =============================================================================================
+template <typename S>
+__global__ __launch_bounds__(kThreads) void plain_select_kernel(
+    const S* __restrict__ page, int64_t n_rows, const uint32_t* __restrict__ bitmap32,
+    S* __restrict__ batch_values, uint32_t* __restrict__ batch_counts) {
+  const int lane = lane_id();
+  const int64_t n_batches = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int64_t bm_dwords = bitmap_dwords(n_rows);
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t batch = (int64_t)blockIdx.x * kWavesPerBlock + wave_id(); batch < n_batches;
+       batch += stride) {
+    const int64_t d = batch * 64 + lane;
+    uint32_t m = d < bm_dwords ? bitmap32[d] : 0u;
+    const int64_t row0 = batch * kRowsPerTile + (int64_t)lane * 32;
+    const int64_t valid = n_rows - row0;
+    if (valid < 32) m = valid <= 0 ? 0u : (m & ((1u << valid) - 1u));
+    const uint32_t mine = (uint32_t)__builtin_popcount(m);
+    const uint32_t incl = wave_inclusive_scan(mine);
+    const uint32_t count = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t P = incl - mine;
+    const S* src = page + row0;
+    S* dst = batch_values + batch * kRowsPerTile;
+    while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
+      S x[4];
+      bool ok[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ok[e] = m != 0u;
+        x[e] = ok[e] ? src[__builtin_ctz(m)] : (S)0;
+        m &= m - 1u;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (ok[e]) dst[P++] = x[e];
+      }
+    }
+    if (lane == 0) batch_counts[batch] = count;
+  }
+}
+
+ips_status launch_plain_select(int stride_bytes, const void* page, int64_t n_rows,
+                               const uint64_t* bitmap, void* batch_values, uint32_t* batch_counts,
+                               hipStream_t s) {
+  const int64_t n_batches = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  if (n_batches <= 0) return IPS_OK;
+  int64_t want = (n_batches + kWavesPerBlock - 1) / kWavesPerBlock;
+  int64_t cap = (int64_t)device_cus() * 8 * grid_mult();
+  const int grid = (int)(want < cap ? want : cap);
+  if (stride_bytes == 4)
+    hipLaunchKernelGGL((plain_select_kernel<uint32_t>), dim3(grid), dim3(kThreads), 0, s,
+                       reinterpret_cast<const uint32_t*>(page), n_rows,
+                       reinterpret_cast<const uint32_t*>(bitmap),
+                       reinterpret_cast<uint32_t*>(batch_values), batch_counts);
+  else
+    hipLaunchKernelGGL((plain_select_kernel<uint64_t>), dim3(grid), dim3(kThreads), 0, s,
+                       reinterpret_cast<const uint64_t*>(page), n_rows,
+                       reinterpret_cast<const uint32_t*>(bitmap),
+                       reinterpret_cast<uint64_t*>(batch_values), batch_counts);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+// =============================================================================================
 // Bitmap algebra: AndOperate / OrOperate (simple-predicates.h:145-163), resize(n, value),
 // count().
 // =============================================================================================

@@ -256,6 +256,16 @@ ips_status ips_plain_pred(const void* d_page, int64_t n_rows, ips_type type, ips
                           const void* literals, int n_literals, ips_semantics semantics,
                           uint64_t* d_bitmap, ips_stream stream);
 
+/* Late materialisation on a PLAIN page against an existing bitmap: ReadValue(skip) ->
+ * ParquetPlainEncoder::Decode(buffer, size, &val, skip_rows) per selected row
+ * (parquet-common.h:186-190, hdfs-parquet-scanner.cc:1006-1027).  The selected rows' slots
+ * (ips_plain_stride(type) bytes each: int8/int16 stay 4-byte slots) are written per batch exactly
+ * like ips_fle_select writes them: batch b holds d_batch_counts[b] slots at
+ * d_batch_values + b * IPS_BATCH_ROWS * stride, row order kept. */
+ips_status ips_plain_select(const void* d_page, int64_t n_rows, ips_type type,
+                            const uint64_t* d_bitmap, void* d_batch_values,
+                            uint32_t* d_batch_counts, ips_stream stream);
+
 /* ---- bitmap algebra (SimplePredicate tree, simple-predicates.h:145-163) --------------------- */
 ips_status ips_bitmap_and(uint64_t* d_a, const uint64_t* d_b, int64_t n_rows, ips_stream stream);
 ips_status ips_bitmap_or(uint64_t* d_a, const uint64_t* d_b, int64_t n_rows, ips_stream stream);

@@ -525,3 +525,34 @@ def test_entry_points_capture_into_a_graph(capi, O):
     assert np.array_equal(bits_of(words(bm_chain[:W]), n), (a2 >= 100) & (a2 < 3000) & (b < 40))
     assert np.array_equal(bits_of(words(bm_tree[:W]), n),
                           ((a2 < 500) & (b >= 10)) | ((a2 >= 3500) & (b < 5)))
+
+
+@pytest.mark.parametrize("type_name", TYPES)
+def test_plain_select(capi, O, type_name):
+    """Late materialisation on PLAIN pages: the slots of the rows a bitmap selects, per batch, in
+    row order (== the reference's Decode(.., skip_rows) walk over the skip list)."""
+    t = getattr(O, type_name)
+    rng = np.random.default_rng(500 + t)
+    for n in (1, 31, 2048, 2049, 70003):
+        npt = O.NP_TYPES[t]
+        vals = (rng.integers(-100, 100, n).astype(npt) if np.issubdtype(npt, np.integer)
+                else rng.normal(0, 50, n).astype(npt))
+        page = O.plain_encode(vals, t)
+        d_page = torch.from_numpy(np.concatenate([page, np.zeros(16, np.uint8)])).cuda()
+        for sel_p in (0.0, 0.03, 0.5, 1.0):
+            sel = rng.random(n) < sel_p
+            bm_words = np.zeros((n + 63) // 64 + 2, np.uint64)
+            idx = np.nonzero(sel)[0]
+            np.bitwise_or.at(bm_words, idx >> 6, np.uint64(1) << (idx & 63).astype(np.uint64))
+            bm_words[-2:] = np.uint64(0xFFFFFFFFFFFFFFFF)            # dirt behind the last word
+            if n % 64:
+                bm_words[(n - 1) >> 6] |= ~np.uint64(0) << np.uint64(n % 64)   # dirt beyond n_rows
+            bm = torch.from_numpy(bm_words.view(np.int64)).cuda()
+            bvals, counts = capi.plain_select(d_page, n, t, bm)
+            c = counts.cpu().numpy()
+            slots = bvals.cpu().numpy()
+            got = np.concatenate([slots[b * 2048: b * 2048 + c[b]] for b in range(len(c))])
+            stride = len(page) // n
+            exp = page.view({4: np.int32, 8: np.int64}[stride])[sel]
+            assert np.array_equal(got, exp), (type_name, n, sel_p)
+            assert c.sum() == sel.sum()

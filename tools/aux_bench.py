@@ -61,3 +61,7 @@ show("assemble_tuples (3 int32 cols -> 16 B tuples)", nsel * (12 + 16) + counts.
      lambda: lib.ips_assemble_tuples(cols, 3, P(counts), N, 16, None, P(tuples), P(cnt), P(ws), S))
 show("fle_select given bitmap (w=32, 10 %)", W * 8 * 33 + 4 * nsel,
      lambda: lib.ips_fle_select(P(enc), N, 32, P(bm), P(bvals), P(counts), S))
+page64 = torch.arange(n, dtype=torch.int64, device=dev)
+bv64 = torch.empty(n, dtype=torch.int64, device=dev)
+show("plain_select int64 given bitmap (10 %)", W * 8 + nsel * 16,
+     lambda: lib.ips_plain_select(P(page64), N, 3, P(bm), P(bv64), P(counts), S))
