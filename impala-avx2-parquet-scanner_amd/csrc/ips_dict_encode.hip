@@ -35,11 +35,26 @@ __device__ __forceinline__ uint64_t slot_bits(const S* values, int64_t i) {
   return KB >= 8 ? raw : raw & ((1ull << (KB * 8 % 64)) - 1);
 }
 
+// Both passes are random-access bound in HBM/L2 (one lane per clock through the texture path), so
+// every workgroup keeps a small front table in LDS: 4096 slots, 4 probes.  A column with up to a
+// few thousand distinct values is then served almost entirely from LDS.
+constexpr uint32_t kFrontSlots = 4096;
+constexpr int kFrontProbes = 4;
+
+__device__ __forceinline__ uint32_t front_hash(uint64_t bits) {
+  uint32_t x = (uint32_t)bits ^ ((uint32_t)(bits >> 32) * 0x9E3779B1u);
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13;
+  return x;
+}
+
 // counters: [0] distinct entries, [1] the all-ones pattern occurred (it is the table's EMPTY mark)
 template <typename S, int KB>
-__global__ void dict_insert_kernel(const S* __restrict__ values, int64_t n,
-                                   unsigned long long* __restrict__ table,
-                                   unsigned int* __restrict__ counters) {
+__global__ __launch_bounds__(256) void dict_insert_kernel(const S* __restrict__ values, int64_t n,
+                                                          unsigned long long* __restrict__ table,
+                                                          unsigned int* __restrict__ counters) {
+  __shared__ unsigned long long front[kFrontSlots];  // keys already known to be in the table
+  for (uint32_t i = threadIdx.x; i < kFrontSlots; i += blockDim.x) front[i] = kEmpty;
+  __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     const uint64_t bits = slot_bits<S, KB>(values, i);
@@ -47,6 +62,17 @@ __global__ void dict_insert_kernel(const S* __restrict__ values, int64_t n,
       counters[1] = 1u;
       continue;
     }
+    const uint32_t fh = front_hash(bits);
+    bool known = false;
+    int free_slot = -1;
+#pragma unroll
+    for (int pr = 0; pr < kFrontProbes; ++pr) {
+      const uint32_t fs = (fh + pr) & (kFrontSlots - 1);
+      const unsigned long long k = front[fs];
+      if (k == bits) { known = true; break; }
+      if (k == kEmpty) { free_slot = (int)fs; break; }
+    }
+    if (known) continue;
     uint32_t h = hash64(bits) & (kTableSlots - 1);
     for (uint32_t probe = 0; probe < kTableSlots; ++probe) {
       unsigned long long seen = table[h];
@@ -62,22 +88,49 @@ __global__ void dict_insert_kernel(const S* __restrict__ values, int64_t n,
       h = (h + 1) & (kTableSlots - 1);
       if (counters[0] > (unsigned)kMaxEntries) break;  // over the cap: the caller gives up anyway
     }
+    // remember it (losing the race for the slot to another key only costs a later global probe)
+    if (free_slot >= 0) atomicCAS(&front[free_slot], (unsigned long long)kEmpty, (unsigned long long)bits);
   }
 }
 
+// Front table of the lookup pass: key and code of a slot travel in ONE 64-bit word when the key
+// has at most 4 bytes (code << 32 | key; codes are < 40000 so the all-ones word is free to mean
+// empty).  8-byte keys go to the global table directly.
 template <typename S, int KB>
-__global__ void dict_lookup_kernel(const S* __restrict__ values, int64_t n,
-                                   const unsigned long long* __restrict__ table,
-                                   const uint32_t* __restrict__ code_of_slot, uint32_t code_of_ones,
-                                   uint32_t* __restrict__ codes) {
+__global__ __launch_bounds__(256) void dict_lookup_kernel(
+    const S* __restrict__ values, int64_t n, const unsigned long long* __restrict__ table,
+    const uint32_t* __restrict__ code_of_slot, uint32_t code_of_ones, uint32_t* __restrict__ codes) {
+  constexpr bool kFront = KB <= 4;
+  __shared__ unsigned long long front[kFront ? kFrontSlots : 1];
+  if (kFront) {
+    for (uint32_t i = threadIdx.x; i < kFrontSlots; i += blockDim.x) front[i] = kEmpty;
+    __syncthreads();
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     const uint64_t bits = slot_bits<S, KB>(values, i);
     uint32_t code = code_of_ones;
     if (bits != kEmpty) {
-      uint32_t h = hash64(bits) & (kTableSlots - 1);
-      while (table[h] != bits) h = (h + 1) & (kTableSlots - 1);  // present by construction
-      code = code_of_slot[h];
+      bool hit = false;
+      int free_slot = -1;
+      if (kFront) {
+        const uint32_t fh = front_hash(bits);
+#pragma unroll
+        for (int pr = 0; pr < kFrontProbes; ++pr) {
+          const uint32_t fs = (fh + pr) & (kFrontSlots - 1);
+          const unsigned long long e = front[fs];
+          if (e == kEmpty) { free_slot = (int)fs; break; }
+          if ((uint32_t)e == (uint32_t)bits) { code = (uint32_t)(e >> 32); hit = true; break; }
+        }
+      }
+      if (!hit) {
+        uint32_t h = hash64(bits) & (kTableSlots - 1);
+        while (table[h] != bits) h = (h + 1) & (kTableSlots - 1);  // present by construction
+        code = code_of_slot[h];
+        if (kFront && free_slot >= 0)
+          atomicCAS(&front[free_slot], (unsigned long long)kEmpty,
+                    ((unsigned long long)code << 32) | (unsigned long long)(uint32_t)bits);
+      }
     }
     codes[i] = code;
   }
