@@ -722,7 +722,10 @@ constexpr int kTupleImageMax = 128;  // tuples up to this size are staged throug
 // lanes.  Every tuple starts as a copy of the template tuple (InitTuple()).  IMAGE = false (tuples
 // wider than 128 bytes or not a multiple of 4): each lane copies the template and writes its slots
 // straight to HBM.
-template <bool IMAGE>
+// FAST: every column REQUIRED, 4 bytes wide and 4-byte aligned in the tuple (the common layout):
+// the column loop is unrolled with constant indices, all slot loads of a round are issued before
+// the first one is consumed.
+template <bool IMAGE, bool FAST>
 __global__ __launch_bounds__(kThreads) void assemble_tuples_kernel(
     TupleCols tc, const uint32_t* __restrict__ counts, int64_t n_batches,
     const uint64_t* __restrict__ batch_off, uint8_t* __restrict__ tuples) {
@@ -747,7 +750,18 @@ __global__ __launch_bounds__(kThreads) void assemble_tuples_kernel(
       } else if (i < cnt) {
         for (int d = 0; d < ts; ++d) t[d] = tc.d_template[d];
       }
-      if (i < cnt) {
+      if (FAST) {
+        uint32_t x[IPS_TUPLE_MAX_COLS];
+        const uint64_t src = (uint64_t)batch * kRowsPerTile + i;
+#pragma unroll
+        for (int col = 0; col < IPS_TUPLE_MAX_COLS; ++col)
+          x[col] = (col < tc.n_cols && i < cnt) ? reinterpret_cast<const uint32_t*>(tc.values[col])[src] : 0u;
+        if (i < cnt) {
+#pragma unroll
+          for (int col = 0; col < IPS_TUPLE_MAX_COLS; ++col)
+            if (col < tc.n_cols) *reinterpret_cast<uint32_t*>(t + tc.offset[col]) = x[col];
+        }
+      } else if (i < cnt) {
         const uint64_t gi = first + i;  // index of this tuple among all selected rows
         for (int col = 0; col < tc.n_cols; ++col) {
           uint64_t src = (uint64_t)batch * kRowsPerTile + i;
@@ -858,13 +872,20 @@ ips_status launch_assemble_tuples(const ips_tuple_column* cols, int n_cols, cons
   ips_status st = launch_batch_offsets(counts, n_batches, total, workspace, &batch_off, s);
   if (st != IPS_OK) return st;
   const int grid = per_batch_grid(n_batches);
-  if (image)
-    hipLaunchKernelGGL(assemble_tuples_kernel<true>, dim3(grid), dim3(kThreads),
-                       (size_t)kWavesPerBlock * kWave * tuple_size, s, tc, counts, n_batches,
-                       batch_off, reinterpret_cast<uint8_t*>(tuples));
+  bool fast = image;
+  for (int i = 0; i < n_cols; ++i)
+    fast = fast && !cols[i].d_nonnull_flags && cols[i].value_width == 4 && (cols[i].tuple_offset & 3) == 0;
+  const size_t lds = image ? (size_t)kWavesPerBlock * kWave * tuple_size : 0;
+  uint8_t* out = reinterpret_cast<uint8_t*>(tuples);
+  if (fast)
+    hipLaunchKernelGGL((assemble_tuples_kernel<true, true>), dim3(grid), dim3(kThreads), lds, s, tc,
+                       counts, n_batches, batch_off, out);
+  else if (image)
+    hipLaunchKernelGGL((assemble_tuples_kernel<true, false>), dim3(grid), dim3(kThreads), lds, s,
+                       tc, counts, n_batches, batch_off, out);
   else
-    hipLaunchKernelGGL(assemble_tuples_kernel<false>, dim3(grid), dim3(kThreads), 0, s, tc, counts,
-                       n_batches, batch_off, reinterpret_cast<uint8_t*>(tuples));
+    hipLaunchKernelGGL((assemble_tuples_kernel<false, false>), dim3(grid), dim3(kThreads), 0, s, tc,
+                       counts, n_batches, batch_off, out);
   IPS_HIP_TRY(hipGetLastError());
   return IPS_OK;
 }
