@@ -137,12 +137,47 @@ __device__ __forceinline__ void fle_scan_body(
 
     uint32_t count = 0;
     if (__builtin_amdgcn_ballot_w64(bm != 0u) != 0ull) {  // wave-uniform: any row selected
-      if (!kInTable) planes_to_values<W>(p, v);
       const uint32_t mine = (uint32_t)__builtin_popcount(bm);
       const uint32_t incl = wave_inclusive_scan(mine);
       count = __builtin_amdgcn_readlane(incl, 63);
       uint32_t P = incl - mine;  // this lane's first output slot inside the batch
       GT* dst = batch_values + tile * kRowsPerTile;
+      // Narrow columns, few selected rows per lane: pick the W bits of each selected row straight
+      // out of the plane registers (2 ops per plane and row) instead of transposing all 32 rows
+      // and going through the row tile -- a narrow sub-tile is only 256*W bytes of HBM time, so
+      // the transposes and the walk are what bounds it.
+      constexpr uint32_t kGatherLaneMax = W <= 4 ? 12 : W <= 8 ? 8 : W <= 12 ? 5 : W <= 16 ? 4 : 0;
+      if (!kInTable && kGatherLaneMax != 0 &&
+          __builtin_amdgcn_ballot_w64(mine > kGatherLaneMax) == 0ull) {
+        uint32_t m = bm;
+        int bad = 0;
+#pragma unroll 1
+        for (uint32_t round = 0; round < kGatherLaneMax; ++round) {
+          if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) break;
+          const bool ok = m != 0u;
+          const uint32_t sh = 31u - (ok ? (uint32_t)__builtin_ctz(m) : 0u);  // row j sits at bit 31-j
+          m &= m - 1u;
+          uint32_t val = 0u;
+#pragma unroll
+          for (int k = 0; k < W; ++k) val |= ((p[k] >> sh) & 1u) << k;
+          if (ok) {
+            if (G == 0) {
+              dst[P] = (GT)val;
+            } else if (val < dict_entries) {
+              dst[P] = lookup(val);
+            } else {
+              bad = 1;
+            }
+            ++P;
+          }
+        }
+        if (G != 0 && bad && bad_index) *bad_index = 1;
+        if (lane == 0) batch_counts[tile] = count;
+        wave_lds_fence();  // LDS region is reused by the next sub-tile
+        tile = next;
+        continue;
+      }
+      if (!kInTable) planes_to_values<W>(p, v);
       wave_lds_fence();  // all plane reads precede the overwrite of the same LDS region
       if (__builtin_amdgcn_ballot_w64(mine > kSparseLaneMax) == 0ull) {
         // Sparse path (the common case up to ~15 % selectivity).  Each lane parks its 32 values
