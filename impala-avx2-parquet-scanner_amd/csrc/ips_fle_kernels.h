@@ -146,7 +146,10 @@ __device__ __forceinline__ void fle_scan_body(
       // out of the plane registers (2 ops per plane and row) instead of transposing all 32 rows
       // and going through the row tile -- a narrow sub-tile is only 256*W bytes of HBM time, so
       // the transposes and the walk are what bounds it.
-      constexpr uint32_t kGatherLaneMax = W <= 4 ? 12 : W <= 8 ? 8 : W <= 12 ? 5 : W <= 16 ? 4 : 0;
+      #ifndef IPS_GATHER_WIDE
+#define IPS_GATHER_WIDE 0  // dev knob: rows per lane up to which w > 16 takes this path (measured: off)
+#endif
+      constexpr uint32_t kGatherLaneMax = W <= 4 ? 12 : W <= 8 ? 8 : W <= 12 ? 5 : W <= 16 ? 4 : IPS_GATHER_WIDE;
       if (!kInTable && kGatherLaneMax != 0 &&
           __builtin_amdgcn_ballot_w64(mine > kGatherLaneMax) == 0ull) {
         uint32_t m = bm;
