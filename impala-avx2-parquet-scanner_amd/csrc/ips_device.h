@@ -74,6 +74,14 @@ __device__ __forceinline__ u32x4 stream_load(const u32x4* p) {
 #endif
 }
 
+// The bitmap a kernel produces is not read again by that kernel: storing it with the nt hint keeps
+// it from occupying L2 next to the page stream (predicate kernels -5...-10 %, fused scan neutral).
+#ifdef IPS_NO_NT_BITMAP_STORE
+#define IPS_BITMAP_STORE(p, v) (*(p) = (v))
+#else
+#define IPS_BITMAP_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#endif
+
 template <int MAXLOADS, bool NT = true>
 __device__ __forceinline__ void tile_load(const uint64_t* __restrict__ enc, int64_t tile, int w,
                                           int64_t total_words, int lane, u32x4 (&r)[MAXLOADS]) {

@@ -9,6 +9,7 @@
 
 namespace ips {
 
+
 enum ScanMode { kScanPredicate = 0, kScanGivenBitmap = 1, kScanInList = 2, kScanInTable = 3 };
 
 // Dictionary gather applied while values leave LDS: G = 0 none (store the code / raw value),
@@ -112,7 +113,7 @@ __device__ __forceinline__ void fle_scan_body(
     uint32_t bm;
     if (MODE == kScanInList && W > 16) {  // wide IN: K passes over the planes in LDS, before they enter VGPRs
       bm = finish_bitmap_dword(pred_from_lds(lds32, W, lane, args), tile, lane, n_rows);
-      if (d < bm_dwords) bitmap32[d] = bm;
+      if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, bm);
     }
     uint32_t p[W];
     planes_from_lds<W>(lds32, lane, p);
@@ -120,15 +121,15 @@ __device__ __forceinline__ void fle_scan_body(
     if (kInTable) {  // long list: decode first, one set lookup per value
       planes_to_values<W>(p, v);
       bm = finish_bitmap_dword(bitrev32(in_table_lookup(in_table, v)), tile, lane, n_rows);
-      if (d < bm_dwords) bitmap32[d] = bm;
+      if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, bm);
     }
     if (MODE == kScanInList && W <= 16) {
       bm = finish_bitmap_dword(pred_in_from_regs<W>(p, args.consts, args.n_consts), tile, lane, n_rows);
-      if (d < bm_dwords) bitmap32[d] = bm;
+      if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, bm);
     }
     if (MODE == kScanPredicate) {
       bm = finish_bitmap_dword(pred_from_regs<W>(p, args), tile, lane, n_rows);
-      if (d < bm_dwords) bitmap32[d] = bm;
+      if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, bm);
     } else if (MODE == kScanGivenBitmap) {
       bm = d < bm_dwords ? given_bitmap32[d] : 0u;
       bm = bitrev32(bm);  // finish_bitmap_dword reverses back; only the row mask is wanted
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_w_ker
     if (d < bm_dwords) {
       if (args.combine == 1) bm &= bitmap32[d];
       else if (args.combine == 2) bm |= bitmap32[d];
-      bitmap32[d] = bm;
+      IPS_BITMAP_STORE(bitmap32 + d, bm);
     }
     wave_lds_fence();  // LDS region is reused by the next sub-tile
     tile = next;

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kThreads) void plain_pred_kernel(const S* __restric
     if (lane < U * RPL && wi < n_words) {
       if (lit.combine == 1) mine &= bitmap[wi];
       else if (lit.combine == 2) mine |= bitmap[wi];
-      bitmap[wi] = mine;
+      IPS_BITMAP_STORE(bitmap + wi, mine);
     }
   }
 }
