@@ -82,6 +82,15 @@ __device__ __forceinline__ u32x4 stream_load(const u32x4* p) {
 #define IPS_BITMAP_STORE(p, v) __builtin_nontemporal_store((v), (p))
 #endif
 
+// Full 16-byte-per-lane output streams (decode, encode): written once, never re-read by the kernel
+// (decode -2...-4 %, encode -3...-5 %).  Scattered 4-byte value stores of the scan are the opposite
+// case: they need L2 to merge them, nt makes them 5-15 % slower.
+#ifdef IPS_NO_NT_STREAM_STORE
+#define IPS_STREAM_STORE16(p, v) (*reinterpret_cast<u32x4*>(p) = (v))
+#else
+#define IPS_STREAM_STORE16(p, v) __builtin_nontemporal_store((v), reinterpret_cast<u32x4*>(p))
+#endif
+
 template <int MAXLOADS, bool NT = true>
 __device__ __forceinline__ void tile_load(const uint64_t* __restrict__ enc, int64_t tile, int w,
                                           int64_t total_words, int lane, u32x4 (&r)[MAXLOADS]) {

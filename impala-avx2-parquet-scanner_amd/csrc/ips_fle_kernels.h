@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_decode_ker
         u32x4 t = *reinterpret_cast<const u32x4*>(lds32 + row_tile_dw(rho));
         int64_t valid = n_rows - (row_base + rho);
         if (valid >= 4) {
-          *reinterpret_cast<u32x4*>(dst + rho) = t;
+          IPS_STREAM_STORE16(dst + rho, t);
         } else {
           if (valid > 0) dst[rho] = t.x;
           if (valid > 1) dst[rho + 1] = t.y;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_decode_ker
         int64_t valid = n_rows - (row_base + rho);
         if (valid >= 8) {
           u32x4 t = {a.x | (a.y << 16), a.z | (a.w << 16), b.x | (b.y << 16), b.z | (b.w << 16)};
-          *reinterpret_cast<u32x4*>(dst + rho) = t;
+          IPS_STREAM_STORE16(dst + rho, t);
         } else {
           uint32_t e[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_decode_ker
           t.y = q[1].x | (q[1].y << 8) | (q[1].z << 16) | (q[1].w << 24);
           t.z = q[2].x | (q[2].y << 8) | (q[2].z << 16) | (q[2].w << 24);
           t.w = q[3].x | (q[3].y << 8) | (q[3].z << 16) | (q[3].w << 24);
-          *reinterpret_cast<u32x4*>(dst + rho) = t;
+          IPS_STREAM_STORE16(dst + rho, t);
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_encode_ker
           t.x = lo.x; t.y = lo.y; t.z = hi.x; t.w = hi.y;
         }
         if (2 * c + 1 < left) {
-          *reinterpret_cast<u32x4*>(enc + w0 + 2 * c) = t;
+          IPS_STREAM_STORE16(enc + w0 + 2 * c, t);
         } else {
           u32x2 h = {t.x, t.y};
           *reinterpret_cast<u32x2*>(enc + w0 + 2 * c) = h;
