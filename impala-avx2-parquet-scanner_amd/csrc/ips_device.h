@@ -64,7 +64,7 @@ __device__ __forceinline__ uint32_t bit_mask(uint32_t c, int k) {
 // 16-byte load of data that is read exactly once (column pages): the nt hint keeps the stream from
 // displacing the kernel's own dirty output lines in L2, so those leave for HBM in larger bursts.
 // Measured on the headline scan: 252 -> 224 us, predicate only: 204 -> 180 us (2^28 rows, w=32).
-// Kernels whose output is as large as their input (decode) are better off without it (+4 %).
+// (With plain stores, kernels whose output is as large as their input measured 4 % slower with it.)
 template <bool NT = true>
 __device__ __forceinline__ u32x4 stream_load(const u32x4* p) {
 #ifdef IPS_NO_NT_LOADS
