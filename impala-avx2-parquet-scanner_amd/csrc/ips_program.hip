@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kThreads) void program_kernel(Program prog, int64_t
       }
     }
     const int64_t d = tile * 64 + lane;
-    if (d < bm_dwords) bitmap32[d] = top;
+    if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, top);
   }
 #endif
 }
