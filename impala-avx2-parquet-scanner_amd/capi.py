@@ -40,7 +40,7 @@ SYMBOLS = [
     "ips_assemble_workspace_bytes", "ips_bitmap_compress",
     "ips_dict_open", "ips_dict_close", "ips_dict_num_entries", "ips_dict_bit_width", "ips_dict_encode",
     "ips_dict_translate", "ips_dict_pred", "ips_dict_decode", "ips_dict_scan", "ips_dict_select",
-    "ips_plain_stride", "ips_plain_pred", "ips_plain_select",
+    "ips_plain_stride", "ips_plain_pred", "ips_plain_scan", "ips_plain_select",
     "ips_bitmap_and", "ips_bitmap_or", "ips_bitmap_fill", "ips_bitmap_count",
     "ips_expand_workspace_bytes", "ips_bitmap_expand",
     "ips_eval_program", "ips_synth_splitmix_u32",
@@ -412,6 +412,21 @@ def bitmap_expand(root, sub, n_rows, stream=None):
     _ck(lib().ips_bitmap_expand(_ptr(root), _ptr(sub), C.c_int64(n_rows), _ptr(out), _ptr(ws),
                                 _stream(stream)))
     return out[:_words(n_rows)]
+
+
+def plain_scan(page, n_rows, type_, op, literals, semantics=None, op2=None, literal2=None, stream=None):
+    """-> (bitmap words, batch slots, batch counts): predicate and selected slots in one pass."""
+    stride = int(lib().ips_plain_stride(type_))
+    dt = torch.int32 if stride == 4 else torch.int64
+    bitmap, bvals, counts = alloc_scan_outputs(n_rows, page.device, dt)
+    v = np.ascontiguousarray(np.atleast_1d(literals), dtype=NP_TYPES[type_])
+    v2 = None if literal2 is None else np.ascontiguousarray(np.atleast_1d(literal2), dtype=NP_TYPES[type_])
+    _ck(lib().ips_plain_scan(_ptr(page), C.c_int64(n_rows), type_, op, v.ctypes.data_as(C.c_void_p),
+                             len(v), 0 if op2 is None else op2,
+                             None if v2 is None else v2.ctypes.data_as(C.c_void_p),
+                             SEM_SQL if semantics is None else semantics, _ptr(bitmap), _ptr(bvals),
+                             _ptr(counts), _stream(stream)))
+    return bitmap[:_words(n_rows)], bvals, counts[:n_batches(n_rows)]
 
 
 def plain_select(page, n_rows, type_, bitmap, stream=None):

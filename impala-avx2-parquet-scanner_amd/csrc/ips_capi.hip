@@ -720,6 +720,39 @@ ips_status ips_plain_pred(const void* d_page, int64_t n_rows, ips_type type, ips
   return launch_plain_pred(type, d_page, n_rows, eff, literals, n_literals, d_bitmap, S(stream));
 }
 
+ips_status ips_plain_scan(const void* d_page, int64_t n_rows, ips_type type, ips_op op,
+                          const void* literals, int n_literals, ips_op op2, const void* literal2,
+                          ips_semantics semantics, uint64_t* d_bitmap, void* d_batch_values,
+                          uint32_t* d_batch_counts, ips_stream stream) {
+  IPS_REQUIRE(valid_type(type), "ips_plain_scan: bad type %d", (int)type);
+  IPS_REQUIRE(op >= IPS_OP_EQ && op <= IPS_OP_IN, "ips_plain_scan: bad op %d", (int)op);
+  IPS_REQUIRE(n_rows >= 0, "ips_plain_scan: n_rows < 0");
+  IPS_REQUIRE(literals && n_literals >= 1 && n_literals <= 16, "ips_plain_scan: 1..16 literals");
+  IPS_REQUIRE(op == IPS_OP_IN || n_literals == 1, "ips_plain_scan: op takes exactly one literal");
+  IPS_REQUIRE(!literal2 || (op != IPS_OP_IN && op2 >= IPS_OP_EQ && op2 <= IPS_OP_GE),
+              "ips_plain_scan: the second comparison must be EQ..GE on a non-IN first one");
+  IPS_REQUIRE(semantics == IPS_SEM_REFERENCE || semantics == IPS_SEM_SQL, "ips_plain_scan: bad semantics");
+  if (op == IPS_OP_IN && semantics == IPS_SEM_REFERENCE) {
+    set_error("ips_plain_scan: IN has no reference behaviour on PLAIN pages (empty body, parquet-common.h:252-255)");
+    return IPS_ERR_UNSUPPORTED;
+  }
+  IPS_REQUIRE(n_rows == 0 || (d_page && aligned16(d_page) && d_bitmap && aligned16(d_bitmap) &&
+                              d_batch_values && aligned16(d_batch_values) && d_batch_counts),
+              "ips_plain_scan: NULL or misaligned argument");
+  if (n_rows == 0) return IPS_OK;
+  auto flip = [&](int o) {  // REFERENCE: literal OP x  ==  x OP' literal
+    if (semantics != IPS_SEM_REFERENCE) return o;
+    if (o == IPS_OP_LT) return (int)IPS_OP_GT;
+    if (o == IPS_OP_GT) return (int)IPS_OP_LT;
+    if (o == IPS_OP_LE) return (int)IPS_OP_GE;
+    if (o == IPS_OP_GE) return (int)IPS_OP_LE;
+    return o;
+  };
+  return launch_plain_scan(type, d_page, n_rows, flip(op), literals, n_literals, literal2 ? 1 : 0,
+                           literal2 ? flip(op2) : 0, literal2, d_bitmap, d_batch_values,
+                           d_batch_counts, S(stream));
+}
+
 ips_status ips_plain_select(const void* d_page, int64_t n_rows, ips_type type,
                             const uint64_t* d_bitmap, void* d_batch_values,
                             uint32_t* d_batch_counts, ips_stream stream) {

@@ -49,6 +49,10 @@ ips_status launch_fle_pred(int w, const uint64_t* enc, int64_t n_rows, const Pre
                            uint32_t* bitmap32, hipStream_t s);
 // combine: 0 set / 1 and-into / 2 or-into the bitmap; join/op2/literal2: second predicate on the
 // same column evaluated in the same pass (0 = none)
+ips_status launch_plain_scan(int type, const void* page, int64_t n_rows, int op, const void* literals,
+                             int n_literals, int join, int op2, const void* literal2,
+                             uint64_t* bitmap, void* batch_values, uint32_t* batch_counts,
+                             hipStream_t s);
 ips_status launch_plain_select(int stride_bytes, const void* page, int64_t n_rows,
                                const uint64_t* bitmap, void* batch_values, uint32_t* batch_counts,
                                hipStream_t s);

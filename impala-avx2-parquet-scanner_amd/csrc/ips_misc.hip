@@ -141,6 +141,150 @@ __global__ __launch_bounds__(kThreads) void plain_pred_kernel(const S* __restric
   }
 }
 
+// Fused scan of a PLAIN page: the predicate's bitmap AND the selected rows' slots in one pass over
+// the page (EvalSimplePredicates + ReadValue(skip) on the same column, hdfs-parquet-scanner.cc:
+// 1837-1865, 1006-1027; parquet-common.h:186-250).  A wave takes one 2048-row batch per iteration
+// (8 or 16 chunks of 16 bytes per lane); per chunk the lanes' selected slots are ranked with a DPP
+// prefix sum and stored straight to the batch, so row order is kept: chunk, lane, element.
+template <typename T, typename S>
+__global__ __launch_bounds__(kThreads) void plain_scan_kernel(const S* __restrict__ page,
+                                                              int64_t n_rows, int op,
+                                                              PlainLit<T> lit,
+                                                              uint64_t* __restrict__ bitmap,
+                                                              S* __restrict__ batch_values,
+                                                              uint32_t* __restrict__ batch_counts) {
+  constexpr int RPL = 16 / sizeof(S);           // rows per lane per load: 4 or 2
+  constexpr int U = kRowsPerTile / (64 * RPL);  // chunks per batch: 8 or 16
+  const int lane = lane_id();
+  const int64_t waves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t rows_per_chunk = 64 * RPL;
+  const int64_t n_batches = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int64_t n_words = (n_rows + 63) / 64;
+
+  for (int64_t batch = (int64_t)blockIdx.x * kWavesPerBlock + wave_id(); batch < n_batches;
+       batch += waves) {
+    const int64_t batch_row0 = batch * kRowsPerTile;
+    uint64_t mine = 0;
+    uint32_t base = 0;  // selected rows of the batch so far (wave-uniform)
+    S* dst = batch_values + batch_row0;
+    constexpr int UH = 8;  // chunks per round: 8 KiB in flight per wave, 32 page registers per lane
+#pragma unroll 1
+    for (int h = 0; h < U / UH; ++h) {
+      const int64_t round_row0 = batch_row0 + (int64_t)h * UH * rows_per_chunk;
+      S raw[UH][RPL];
+      if (round_row0 + UH * rows_per_chunk <= n_rows) {  // wave-uniform: full round
+#pragma unroll
+        for (int u = 0; u < UH; ++u) {
+          u32x4 t = stream_load(reinterpret_cast<const u32x4*>(page + round_row0 + u * rows_per_chunk + lane * RPL));
+          __builtin_memcpy(raw[u], &t, 16);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < UH; ++u) {
+          const int64_t row0 = round_row0 + u * rows_per_chunk + (int64_t)lane * RPL;
+#pragma unroll
+          for (int e = 0; e < RPL; ++e) raw[u][e] = row0 + e < n_rows ? page[row0 + e] : (S)0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UH; ++u) {
+        const int64_t row0 = round_row0 + u * rows_per_chunk + (int64_t)lane * RPL;
+        uint64_t m[RPL];
+        bool sel_e[RPL];
+#pragma unroll
+        for (int e = 0; e < RPL; ++e) {
+          const T x = slot_value<T, S>(raw[u][e]);
+          bool b = plain_cmp<T>(x, op, lit);
+          if (lit.join != 0) {
+            PlainLit<T> l2;
+            l2.v[0] = lit.v2;
+            l2.n = 1;
+            const bool b2 = plain_cmp<T>(x, lit.op2, l2);
+            b = lit.join == 1 ? (b && b2) : (b || b2);
+          }
+          b = b && (row0 + e < n_rows);
+          sel_e[e] = b;
+          m[e] = __builtin_amdgcn_ballot_w64(b);  // bit l <-> row RPL*l + e of the chunk
+        }
+        // bitmap words of the chunk (row 64*j + t sits in ballot (t % RPL) at bit (64*j + t) / RPL)
+        uint64_t sel;
+        if (RPL == 4) sel = (lane & 2) ? ((lane & 1) ? m[3] : m[2]) : ((lane & 1) ? m[1] : m[0]);
+        else sel = (lane & 1) ? m[1] : m[0];
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+          int src = (64 * j + lane) / RPL;
+          uint64_t word = __builtin_amdgcn_ballot_w64(((sel >> src) & 1ull) != 0ull);
+          if (lane == (h * UH + u) * RPL + j) mine = word;
+        }
+        // selected slots of the chunk, in row order.  The ballots already hold everything a prefix
+        // sum would compute: rows selected in lower lanes = mbcnt of each ballot, chunk total =
+        // scalar popcounts.
+        if ((m[0] | m[1] | (RPL == 4 ? (m[RPL - 2] | m[RPL - 1]) : 0ull)) != 0ull) {  // wave-uniform
+          uint32_t P = base;
+          uint32_t total = 0;
+#pragma unroll
+          for (int e = 0; e < RPL; ++e) {
+            P += __builtin_amdgcn_mbcnt_hi((uint32_t)(m[e] >> 32),
+                                           __builtin_amdgcn_mbcnt_lo((uint32_t)m[e], 0u));
+            total += (uint32_t)__builtin_popcountll(m[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < RPL; ++e)
+            if (sel_e[e]) dst[P++] = raw[u][e];
+          base += total;
+        }
+      }
+    }
+    const int64_t wi = batch * 32 + lane;
+    if (lane < 32 && wi < n_words) IPS_BITMAP_STORE(bitmap + wi, mine);
+    if (lane == 0) batch_counts[batch] = base;
+  }
+}
+
+template <typename T, typename S>
+static ips_status launch_plain_scan_t(const void* page, int64_t n_rows, int op, const void* literals,
+                                      int n_literals, int join, int op2, const void* literal2,
+                                      uint64_t* bitmap, void* batch_values, uint32_t* batch_counts,
+                                      hipStream_t s) {
+  PlainLit<T> lit;
+  lit.n = n_literals;
+  lit.combine = 0;
+  lit.join = join;
+  lit.op2 = op2;
+  lit.v2 = literal2 ? *reinterpret_cast<const T*>(literal2) : T();
+  for (int i = 0; i < 16; ++i) lit.v[i] = i < n_literals ? reinterpret_cast<const T*>(literals)[i] : T();
+  const int64_t n_batches = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  int64_t want = (n_batches + kWavesPerBlock - 1) / kWavesPerBlock;
+  int64_t cap = (int64_t)device_cus() * 4 * grid_mult();
+  int grid = (int)(want < cap ? want : cap);
+  if (grid <= 0) return IPS_ERR_HIP;
+  hipLaunchKernelGGL((plain_scan_kernel<T, S>), dim3(grid), dim3(kThreads), 0, s,
+                     reinterpret_cast<const S*>(page), n_rows, op, lit, bitmap,
+                     reinterpret_cast<S*>(batch_values), batch_counts);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+ips_status launch_plain_scan(int type, const void* page, int64_t n_rows, int op, const void* literals,
+                             int n_literals, int join, int op2, const void* literal2,
+                             uint64_t* bitmap, void* batch_values, uint32_t* batch_counts,
+                             hipStream_t s) {
+#define IPS_PS(T, S)                                                                              \
+  return launch_plain_scan_t<T, S>(page, n_rows, op, literals, n_literals, join, op2, literal2, \
+                                   bitmap, batch_values, batch_counts, s)
+  switch (type) {
+    case IPS_T_INT8: IPS_PS(int8_t, int32_t);
+    case IPS_T_INT16: IPS_PS(int16_t, int32_t);
+    case IPS_T_INT32: IPS_PS(int32_t, int32_t);
+    case IPS_T_INT64: IPS_PS(int64_t, int64_t);
+    case IPS_T_FLOAT: IPS_PS(float, int32_t);
+    case IPS_T_DOUBLE: IPS_PS(double, int64_t);
+  }
+#undef IPS_PS
+  set_error("plain_scan: bad type %d", type);
+  return IPS_ERR_INVALID_ARG;
+}
+
 template <typename T, typename S>
 static ips_status launch_plain_t(const void* page, int64_t n_rows, int op, const void* literals,
                                  int n_literals, uint64_t* bitmap, hipStream_t s, int combine,

@@ -256,6 +256,16 @@ ips_status ips_plain_pred(const void* d_page, int64_t n_rows, ips_type type, ips
                           const void* literals, int n_literals, ips_semantics semantics,
                           uint64_t* d_bitmap, ips_stream stream);
 
+/* Fused scan of a PLAIN page: bitmap of (x op literal) [AND (x op2 literal2) when literal2 != NULL:
+ * a BETWEEN as And(Ge, Le), simple-predicates.h:145-153] plus the selected rows' slots, one pass over
+ * the page -- EvalSimplePredicates + ReadValue(skip) on the same PLAIN column
+ * (hdfs-parquet-scanner.cc:1837-1865, 1006-1027; parquet-common.h:186-250).  Outputs as
+ * ips_plain_select / ips_fle_scan lay them out (slots of ips_plain_stride(type) bytes). */
+ips_status ips_plain_scan(const void* d_page, int64_t n_rows, ips_type type, ips_op op,
+                          const void* literals, int n_literals, ips_op op2, const void* literal2,
+                          ips_semantics semantics, uint64_t* d_bitmap, void* d_batch_values,
+                          uint32_t* d_batch_counts, ips_stream stream);
+
 /* Late materialisation on a PLAIN page against an existing bitmap: ReadValue(skip) ->
  * ParquetPlainEncoder::Decode(buffer, size, &val, skip_rows) per selected row
  * (parquet-common.h:186-190, hdfs-parquet-scanner.cc:1006-1027).  The selected rows' slots

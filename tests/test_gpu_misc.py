@@ -556,3 +556,39 @@ def test_plain_select(capi, O, type_name):
             exp = page.view({4: np.int32, 8: np.int64}[stride])[sel]
             assert np.array_equal(got, exp), (type_name, n, sel_p)
             assert c.sum() == sel.sum()
+
+
+@pytest.mark.parametrize("type_name", TYPES)
+def test_plain_scan(capi, O, type_name):
+    """Fused PLAIN scan == ips_plain_pred (oracle-checked) + ips_plain_select, for single
+    comparisons, a BETWEEN pair and an IN list, under both operand-order semantics."""
+    t = getattr(O, type_name)
+    npt = O.NP_TYPES[t]
+    rng = np.random.default_rng(640 + t)
+    for n in (1, 63, 2048, 2049, 70003):
+        vals = (rng.integers(-100, 100, n).astype(npt) if np.issubdtype(npt, np.integer)
+                else rng.normal(0, 50, n).astype(npt))
+        page = O.plain_encode(vals, t)
+        d_page = torch.from_numpy(np.concatenate([page, np.zeros(16, np.uint8)])).cuda()
+        stride = len(page) // n
+        slots = page.view({4: np.int32, 8: np.int64}[stride])
+
+        def check(bitmap, bvals, counts, sel):
+            assert np.array_equal(bits_of(words(bitmap), n), sel)
+            c = counts.cpu().numpy()
+            s_ = bvals.cpu().numpy()
+            got = np.concatenate([s_[b * 2048: b * 2048 + c[b]] for b in range(len(c))])
+            assert np.array_equal(got, slots[sel])
+
+        lit = vals[n // 2]
+        for sem in (O.SEM_SQL, O.SEM_REFERENCE):
+            for op in (O.OP_EQ, O.OP_LT, O.OP_LE, O.OP_GT, O.OP_GE):
+                ref = bits_of(O.plain_pred(page, n, t, op, lit, sem), n)
+                check(*capi.plain_scan(d_page, n, t, op, lit, semantics=sem), ref)
+        lo, hi = np.sort(rng.choice(vals, 2))
+        sel = (vals >= lo) & (vals <= hi)
+        check(*capi.plain_scan(d_page, n, t, O.OP_GE, lo, op2=O.OP_LE, literal2=hi), sel)
+        lst = rng.choice(vals, min(5, n))
+        check(*capi.plain_scan(d_page, n, t, O.OP_IN, lst), np.isin(vals, lst))
+    with pytest.raises(capi.IpsError):
+        capi.plain_scan(d_page, n, t, O.OP_IN, lst, semantics=O.SEM_REFERENCE)
