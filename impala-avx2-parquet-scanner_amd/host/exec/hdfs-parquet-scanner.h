@@ -31,9 +31,23 @@ class HdfsParquetScanner {
     int64_t num_buffered_values() const { return num_buffered_values_; }
     void consume(int64_t n) { num_buffered_values_ -= n; }
     int max_def_level() const { return max_def_level_; }
+    // further data pages of the column chunk, consumed in order when the current one is used up
+    // (ReadDataPage / InitDataPage, .cc:766-916)
+    struct PendingPage { uint8_t* data; int len; int64_t num_values; };
+    void AddPendingPage(uint8_t* data, int len, int64_t num_values) {
+      pending_pages_.push_back(PendingPage{data, len, num_values});
+    }
+    bool NextPage() {
+      if (pending_pages_.empty()) return false;
+      const PendingPage pg = pending_pages_.front();
+      pending_pages_.erase(pending_pages_.begin());
+      return InitDataPage(pg.data, pg.len, pg.num_values);
+    }
    protected:
+    virtual bool InitDataPage(uint8_t* data, int len, int64_t num_values) = 0;
     int64_t num_buffered_values_ = 0;
     int max_def_level_ = 0;
+    std::vector<PendingPage> pending_pages_;
   };
 
   // Per column type reader, hdfs-parquet-scanner.cc:305-567
@@ -135,6 +149,32 @@ class HdfsParquetScanner {
       return true;
     }
 
+   protected:
+    // [int32 n_def_bytes][def levels]? [uint8 width][codes] for dictionary columns, raw slots for
+    // PLAIN ones; the dictionary stays (one dictionary page per column chunk)
+    virtual bool InitDataPage(uint8_t* data, int len, int64_t num_values) {
+      num_buffered_values_ = num_values;
+      if (dict_decoder_) {
+        uint8_t* p = data;
+        int left = len;
+        if (max_def_level_ > 0) {  // .cc:882-901
+          int32_t n_def_bytes;
+          memcpy(&n_def_bytes, p, 4);
+          p += 4; left -= 4;
+          fle_def_levels_.reset(new FleDecoder(p, n_def_bytes, BitUtil::Log2((uint64_t)max_def_level_ + 1)));
+          p += n_def_bytes; left -= n_def_bytes;
+        }
+        dict_decoder_->SetData(p, left);
+        return true;
+      }
+      data_ = plain_begin_ = data;
+      plain_rows_ = num_values;
+      T dummy;
+      data_end_ = data + num_values * ParquetPlainEncoder::ByteSize(dummy);
+      plain_dev_.release();
+      return true;
+    }
+
    private:
     friend class HdfsParquetScanner;
     template <typename D, typename L>
@@ -201,6 +241,11 @@ class HdfsParquetScanner {
     return (int)column_readers_.size() - 1;
   }
 
+  // a further data page of column idx (same dictionary); pages are consumed in the order added
+  void AddDataPage(int idx, uint8_t* data_page, int data_len, int64_t num_values) {
+    column_readers_[(size_t)idx]->AddPendingPage(data_page, data_len, num_values);
+  }
+
   // ---- hdfs-parquet-scanner.h:91-102 ----
   template <typename T> void Eq(int idx, int64_t n, SkipBitset& b, T& val) { reader<T>(idx)->Pred(IPS_OP_EQ, n, b, val); }
   template <typename T> void Lt(int idx, int64_t n, SkipBitset& b, T& val) { reader<T>(idx)->Pred(IPS_OP_LT, n, b, val); }
@@ -220,7 +265,7 @@ class HdfsParquetScanner {
   bool EvalSimplePredicates(SkipBitset& skip_bitset) {
     int64_t limit_rows = 1024;
     for (auto& c : column_readers_) {
-      if (c->num_buffered_values() == 0) return false;  // the reference would read the next page
+      if (c->num_buffered_values() == 0 && !c->NextPage()) return false;  // ReadDataPage, .cc:1846-1850
       if (c->num_buffered_values() < limit_rows) limit_rows = c->num_buffered_values();
     }
     for (auto& c : column_readers_) c->consume(limit_rows);

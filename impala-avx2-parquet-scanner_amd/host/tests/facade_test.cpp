@@ -353,6 +353,115 @@ static void TestScanner() {
   CHECK(unknown_fn.CreateSimplePredicates(&s) == NULL);
 }
 
+// A column chunk as several data pages per column, page boundaries differing between the columns
+// (dictionary int32: 3000 + 5000 + 2011 rows; dictionary OPTIONAL int32: 4000 + 6011; PLAIN int32:
+// 7000 + 3011): the batches stop at every page end of every column (.cc:1839-1850) and the next
+// page is picked up by the following call.
+static void TestScannerMultiPage() {
+  const int n = 10011;
+  std::vector<int32_t> c0(n), c1(n), c2(n);
+  std::vector<bool> c1_null(n);
+  DictEncoder<int32_t> e0, e1;
+  for (int i = 0; i < n; ++i) {
+    c0[i] = (int32_t)(rnd() % 700);
+    c1_null[i] = (rnd() % 7) == 0;
+    c1[i] = (int32_t)(rnd() % 90) - 40;
+    c2[i] = (int32_t)(rnd() % 4000) - 2000;
+    e0.Put(c0[i]);
+    if (!c1_null[i]) e1.Put(c1[i]);
+  }
+  std::vector<uint8_t> d0((size_t)e0.dict_encoded_size() + 8), d1((size_t)e1.dict_encoded_size() + 8);
+  e0.WriteDict(d0.data());
+  e1.WriteDict(d1.data());
+  // one data page = the indices of its rows, written against the finished dictionary
+  auto data_page = [&](DictEncoder<int32_t>& enc, const std::vector<int32_t>& col, const std::vector<bool>* nulls,
+                       int lo, int hi) {
+    enc.ClearIndices();
+    std::vector<uint32_t> defs;
+    for (int i = lo; i < hi; ++i) {
+      const bool is_null = nulls && (*nulls)[(size_t)i];
+      if (!is_null) enc.Put(col[(size_t)i]);
+      defs.push_back(is_null ? 0u : 1u);
+    }
+    std::vector<uint8_t> codes(1 << 18);
+    const int len = enc.WriteData(codes.data(), (int)codes.size());
+    CHECK(len > 0);
+    codes.resize((size_t)len);
+    if (!nulls) return codes;
+    std::vector<uint8_t> defbuf((size_t)ips_fle_encoded_bytes(hi - lo, 1));
+    FleEncoder defenc(defbuf.data(), (int)defbuf.size(), 1);
+    for (uint32_t d : defs) defenc.Put(d);
+    const int32_t n_def_bytes = defenc.Flush();
+    std::vector<uint8_t> page(4 + (size_t)n_def_bytes + codes.size());
+    memcpy(page.data(), &n_def_bytes, 4);
+    memcpy(page.data() + 4, defbuf.data(), (size_t)n_def_bytes);
+    memcpy(page.data() + 4 + n_def_bytes, codes.data(), codes.size());
+    return page;
+  };
+  const int b0[] = {0, 3000, 8000, n}, b1[] = {0, 4000, n}, b2[] = {0, 7000, n};
+  std::vector<std::vector<uint8_t>> p0, p1;
+  for (int k = 0; k < 3; ++k) p0.push_back(data_page(e0, c0, nullptr, b0[k], b0[k + 1]));
+  for (int k = 0; k < 2; ++k) p1.push_back(data_page(e1, c1, &c1_null, b1[k], b1[k + 1]));
+  std::vector<uint8_t> plain((size_t)n * 4);
+  memcpy(plain.data(), c2.data(), plain.size());
+
+  HdfsParquetScanner scanner;
+  scanner.AddDictionaryColumn<int32_t>(d0.data(), e0.dict_encoded_size(), p0[0].data(), (int)p0[0].size(), b0[1] - b0[0]);
+  scanner.AddDictionaryColumn<int32_t>(d1.data(), e1.dict_encoded_size(), p1[0].data(), (int)p1[0].size(), b1[1] - b1[0], 1);
+  scanner.AddPlainColumn<int32_t>(plain.data(), b2[1]);
+  for (int k = 1; k < 3; ++k) scanner.AddDataPage(0, p0[(size_t)k].data(), (int)p0[(size_t)k].size(), b0[k + 1] - b0[k]);
+  scanner.AddDataPage(1, p1[1].data(), (int)p1[1].size(), b1[2] - b1[1]);
+  scanner.AddDataPage(2, plain.data() + (size_t)b2[1] * 4, (n - b2[1]) * 4, n - b2[1]);
+
+  std::vector<ExprContext*> ctxs;
+  ctxs.push_back(new ExprContext(new ScalarFnCall("lt", new SlotRef(TYPE_INT, 0), {new Literal(TYPE_INT, (int64_t)350)})));
+  ctxs.push_back(new ExprContext(new OrPredicate(
+      new ScalarFnCall("ge", new SlotRef(TYPE_INT, 1), {new Literal(TYPE_INT, (int64_t)10)}),
+      new ScalarFnCall("gt", new SlotRef(TYPE_INT, 2), {new Literal(TYPE_INT, (int64_t)1500)}))));
+  std::vector<SimplePredicate*> roots;
+  CHECK(CreateSimplePredicates(&scanner, ctxs, &roots));
+  for (SimplePredicate* r : roots) scanner.AddSimplePredicate(r);
+  auto expect = [&](int i) {
+    // PLAIN leaves use the reference operand order (literal OP x): "gt 1500" means 1500 > x
+    return c0[(size_t)i] < 350 && ((!c1_null[(size_t)i] && c1[(size_t)i] >= 10) || 1500 > c2[(size_t)i]);
+  };
+  // rows left in each column's current page bound every batch
+  const int cuts[] = {3000, 4000, 7000, 8000, n};
+  int64_t row = 0, selected = 0;
+  int batches = 0;
+  while (row < n) {
+    SkipBitset bs;
+    CHECK(scanner.EvalSimplePredicates(bs));
+    const int64_t batch = (int64_t)bs.size();
+    int64_t to_cut = n - row;
+    for (int c : cuts) if (c > row) { to_cut = c - row; break; }
+    CHECK(batch == std::min<int64_t>(1024, to_cut));
+    if (batch <= 0) break;
+    for (int64_t i = 0; i < batch; ++i) CHECK(bs[(size_t)i] == expect((int)(row + i)));
+    std::vector<int> skip_rows;
+    int last_skip_rows = 0;
+    HdfsParquetScanner::BitsetToSkipList(bs, &skip_rows, &last_skip_rows);
+    int64_t r = row;
+    for (int skip : skip_rows) {
+      r += skip;
+      int32_t v0 = 0, v1 = 0, v2 = 0;
+      bool is_null = false;
+      CHECK(scanner.ReadValue(0, &v0, skip) && v0 == c0[(size_t)r]);
+      CHECK(scanner.ReadValue(1, &v1, skip, &is_null) && is_null == (bool)c1_null[(size_t)r] && (is_null || v1 == c1[(size_t)r]));
+      CHECK(scanner.ReadValue(2, &v2, skip) && v2 == c2[(size_t)r]);
+      ++r; ++selected;
+    }
+    if (last_skip_rows)
+      for (int c = 0; c < 3; ++c) scanner.SkipValue(c, last_skip_rows);
+    row += batch;
+    ++batches;
+  }
+  CHECK(row == n && selected > 100 && batches == 10);  // 3 + 1 + 3 + 1 + 2 batches between the page cuts
+  SkipBitset tail;
+  CHECK(!scanner.EvalSimplePredicates(tail));  // no page left in any column
+  for (ExprContext* c : ctxs) delete c;
+}
+
 // ips_eval_program straight through the C-ABI from a plain C++ process: an OR of two conjunctions
 // needs a temporary bitmap next to d_bitmap (stream-ordered allocation inside the call).
 static void TestProgramWithTemporaryBitmap() {
@@ -413,6 +522,7 @@ int main() {
   TestDictPredicates<int32_t>(); TestDictPredicates<int64_t>(); TestDictPredicates<double>();
   TestDictPredicates<int16_t>(); TestDictPredicates<float>();
   TestScanner();
+  TestScannerMultiPage();
   TestProgramWithTemporaryBitmap();
   CHECK(ips::sticky_status() == IPS_OK);
   printf("facade_test: %d checks, %d failed\n", g_checks, g_fail);
