@@ -364,6 +364,100 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_w_ker
 }
 
 // ---------------------------------------------------------------------------------------------
+// w = 32, single comparison, early pruning.  A block of width 32 is two 128-byte lines: planes
+// 31..16 in the second, 15..0 in the first.  The MSB->LSB recurrence only needs the low planes for
+// rows that are still EQUAL to the constant after the high ones -- on a column that uses its 32
+// bits that is one row in 65536 -- so the wave first loads and evaluates the high lines only (half
+// the bytes) and fetches the low lines of a sub-tile only if some row in it is still undecided.
+// A wave that had to fetch them keeps prefetching both halves until a sub-tile is decided by the
+// high planes again, which bounds the cost on columns whose high bits all equal the constant's.
+// ---------------------------------------------------------------------------------------------
+template <int W>  // W = 32 only (a template so that the header may be included by several units)
+__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_early_kernel(
+    const uint64_t* __restrict__ enc, int64_t n_rows, PredArgs args,
+    uint32_t* __restrict__ bitmap32) {
+  static_assert(W == 32, "two 128-byte lines per block");
+  __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * plane_tile_bytes(W) / 4];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  uint32_t* lds32 = lds_all + wave * (plane_tile_bytes(W) / 4);
+  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int64_t total_words = ((n_rows + 63) / 64) * W;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t bm_dwords = bitmap_dwords(n_rows);
+  const uint32_t c = args.consts[0];
+
+  // half = 1: words 16..31 of every block (planes 31..16), half = 0: words 0..15
+  auto load_half = [&](int64_t tile, int half, u32x4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = i * kWave + lane;                  // 256 chunks of 16 bytes per half tile
+      const int64_t word = tile * (kBlocksPerTile * W) + (ch >> 3) * W + half * 16 + (ch & 7) * 2;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (word + 1 < total_words) v = stream_load(reinterpret_cast<const u32x4*>(enc + word));
+      r[i] = v;                                         // whole blocks only: words come in pairs
+    }
+  };
+  auto stage_half = [&](int half, const u32x4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = i * kWave + lane;
+      uint32_t* dst = lds32 + 2 * ((ch >> 3) * plane_stride_words(W) + half * 16 + (ch & 7) * 2);
+      dst[0] = r[i].x; dst[1] = r[i].y; dst[2] = r[i].z; dst[3] = r[i].w;
+    }
+  };
+  auto planes_step = [&](int half, CmpState& st) {
+    const uint32_t* p = lds32 + plane_base_dw(W, lane);
+    uint32_t x[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = p[2 * (half * 16 + 15 - e)];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cmp_step(st, x[e], bit_mask(c, half * 16 + 15 - e));
+  };
+
+  int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  bool with_low = false;  // wave-uniform: the previous sub-tile needed the low planes
+  u32x4 rh[4], rl[4];
+  if (tile < tiles) load_half(tile, 1, rh);
+  while (tile < tiles) {
+    stage_half(1, rh);
+    const bool have_low = with_low;
+    if (have_low) stage_half(0, rl);
+    const int64_t next = tile + stride;
+    wave_lds_fence();
+    CmpState st{0u, ~0u};
+    planes_step(1, st);
+    // rows beyond n_rows are padding: never let them ask for the low planes
+    const int64_t valid = n_rows - (tile * kRowsPerTile + (int64_t)lane * 32);
+    const uint32_t live = valid >= 32 ? ~0u : valid <= 0 ? 0u : ~((1u << (32 - valid)) - 1u);  // MSB-first rows
+    const bool undecided = __builtin_amdgcn_ballot_w64((st.eq & live) != 0u) != 0ull;
+    if (next < tiles) {  // prefetch: the high half always, the low half while the column needs it
+      load_half(next, 1, rh);
+      if (undecided) load_half(next, 0, rl);
+    }
+    if (undecided) {
+      if (!have_low) {  // demand fetch of this sub-tile's low lines
+        u32x4 now[4];
+        load_half(tile, 0, now);
+        stage_half(0, now);
+        wave_lds_fence();
+      }
+      planes_step(0, st);
+    }
+    with_low = undecided;
+    uint32_t bm = finish_bitmap_dword(cmp_select(st, args.op), tile, lane, n_rows);
+    const int64_t d = tile * 64 + lane;
+    if (d < bm_dwords) {
+      if (args.combine == 1) bm &= bitmap32[d];
+      else if (args.combine == 2) bm |= bitmap32[d];
+      IPS_BITMAP_STORE(bitmap32 + d, bm);
+    }
+    wave_lds_fence();  // LDS region is reused by the next sub-tile
+    tile = next;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Full decode: FleDecoder::Get x n via Unpack_w (fle-encoding.h:404-567, 569-7329), batch form.
 // OW = bytes per stored value (1, 2, 4) when G == 0; with G != 0 every code is looked up in the
 // dictionary and the G-byte entry is stored (DictDecoder::GetValue, dict-encoding.h:310-319).

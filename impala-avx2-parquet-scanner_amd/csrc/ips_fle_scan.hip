@@ -1,5 +1,7 @@
 // ips_fle_scan.hip -- instantiations + launchers of the fused scan / select kernels for the bit
 // widths [IPS_WLO, IPS_WHI] (the file is compiled four times so the build parallelises).
+#include <stdlib.h>
+
 #include "ips_fle_kernels.h"
 #include "ips_host.h"
 
@@ -129,6 +131,18 @@ static ips_status launch_pred_wk(const uint64_t* enc, int64_t n_rows, const Pred
 template <int W>
 static ips_status launch_pred_w(const uint64_t* enc, int64_t n_rows, const PredArgs& args,
                                 uint32_t* bitmap32, hipStream_t s) {
+  if constexpr (W == 32) {
+    static const bool early = getenv("IPS_NO_EARLY_PRUNE") == nullptr;
+    if (early && args.join == 0 && args.op != 5) {
+      const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+      int grid = grid_for_tiles(reinterpret_cast<const void*>(fle_pred32_early_kernel<32>), tiles);
+      if (grid <= 0) return IPS_ERR_HIP;
+      hipLaunchKernelGGL(fle_pred32_early_kernel<32>, dim3(grid), dim3(kThreads), 0, s, enc, n_rows, args,
+                         bitmap32);
+      IPS_HIP_TRY(hipGetLastError());
+      return IPS_OK;
+    }
+  }
   if (args.join != 0) return launch_pred_wk<W, kPredPair>(enc, n_rows, args, bitmap32, s);
   if (args.op == 5) {
     if constexpr (W <= 16) {

@@ -425,8 +425,9 @@ def test_random_predicate_trees(capi, O, strategy, monkeypatch):
         monkeypatch.delenv("IPS_PROGRAM_NO_CHAIN", raising=False)
     rng = np.random.default_rng(4242)
     n = 20000 + 37
-    widths = (5, 12, 20)
-    fle_np = [rng.integers(0, 1 << w, n).astype(np.uint32) for w in widths]
+    widths = (5, 12, 32)   # 32: the early-pruning kernel, also in its and-into / or-into modes
+    fle_np = [rng.integers(0, 1 << w, n, dtype=np.uint64).astype(np.uint32) for w in widths]
+    fle_np[2][::3] &= 0xFFFF   # rows that stay undecided after the high planes
     p32 = rng.integers(-100, 100, n).astype(np.int32)
     p64 = rng.integers(-10 ** 6, 10 ** 6, n).astype(np.int64)
     encs = [dev_words(O.fle_encode(v, w)) for v, w in zip(fle_np, widths)]
