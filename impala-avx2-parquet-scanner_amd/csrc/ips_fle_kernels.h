@@ -372,7 +372,9 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_w_ker
 // A wave that had to fetch them keeps prefetching both halves until a sub-tile is decided by the
 // high planes again, which bounds the cost on columns whose high bits all equal the constant's.
 // ---------------------------------------------------------------------------------------------
-template <int W>  // W = 32 only (a template so that the header may be included by several units)
+// PAIR: two comparisons on the column in the same pass (BETWEEN): a row needs the low planes if it
+// is still equal to either constant.
+template <int W, bool PAIR>  // W = 32 only
 __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_early_kernel(
     const uint64_t* __restrict__ enc, int64_t n_rows, PredArgs args,
     uint32_t* __restrict__ bitmap32) {
@@ -386,6 +388,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_ear
   const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
   const int64_t bm_dwords = bitmap_dwords(n_rows);
   const uint32_t c = args.consts[0];
+  const uint32_t c2 = args.const2;
 
   // half = 1: words 16..31 of every block (planes 31..16), half = 0: words 0..15
   auto load_half = [&](int64_t tile, int half, u32x4 (&r)[4]) {
@@ -406,13 +409,16 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_ear
       dst[0] = r[i].x; dst[1] = r[i].y; dst[2] = r[i].z; dst[3] = r[i].w;
     }
   };
-  auto planes_step = [&](int half, CmpState& st) {
+  auto planes_step = [&](int half, CmpState& st, CmpState& st2) {
     const uint32_t* p = lds32 + plane_base_dw(W, lane);
     uint32_t x[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = p[2 * (half * 16 + 15 - e)];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) cmp_step(st, x[e], bit_mask(c, half * 16 + 15 - e));
+    for (int e = 0; e < 16; ++e) {
+      cmp_step(st, x[e], bit_mask(c, half * 16 + 15 - e));
+      if (PAIR) cmp_step(st2, x[e], bit_mask(c2, half * 16 + 15 - e));
+    }
   };
 
   int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -425,12 +431,13 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_ear
     if (have_low) stage_half(0, rl);
     const int64_t next = tile + stride;
     wave_lds_fence();
-    CmpState st{0u, ~0u};
-    planes_step(1, st);
+    CmpState st{0u, ~0u}, st2{0u, ~0u};
+    planes_step(1, st, st2);
     // rows beyond n_rows are padding: never let them ask for the low planes
     const int64_t valid = n_rows - (tile * kRowsPerTile + (int64_t)lane * 32);
     const uint32_t live = valid >= 32 ? ~0u : valid <= 0 ? 0u : ~((1u << (32 - valid)) - 1u);  // MSB-first rows
-    const bool undecided = __builtin_amdgcn_ballot_w64((st.eq & live) != 0u) != 0ull;
+    const uint32_t open_rows = (PAIR ? (st.eq | st2.eq) : st.eq) & live;
+    const bool undecided = __builtin_amdgcn_ballot_w64(open_rows != 0u) != 0ull;
     if (next < tiles) {  // prefetch: the high half always, the low half while the column needs it
       load_half(next, 1, rh);
       if (undecided) load_half(next, 0, rl);
@@ -442,10 +449,15 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_ear
         stage_half(0, now);
         wave_lds_fence();
       }
-      planes_step(0, st);
+      planes_step(0, st, st2);
     }
     with_low = undecided;
-    uint32_t bm = finish_bitmap_dword(cmp_select(st, args.op), tile, lane, n_rows);
+    uint32_t sel = cmp_select(st, args.op);
+    if (PAIR) {
+      const uint32_t sel2 = cmp_select(st2, args.op2);
+      sel = args.join == 1 ? (sel & sel2) : (sel | sel2);
+    }
+    uint32_t bm = finish_bitmap_dword(sel, tile, lane, n_rows);
     const int64_t d = tile * 64 + lane;
     if (d < bm_dwords) {
       if (args.combine == 1) bm &= bitmap32[d];

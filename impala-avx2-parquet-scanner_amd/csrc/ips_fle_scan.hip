@@ -133,12 +133,12 @@ static ips_status launch_pred_w(const uint64_t* enc, int64_t n_rows, const PredA
                                 uint32_t* bitmap32, hipStream_t s) {
   if constexpr (W == 32) {
     static const bool early = getenv("IPS_NO_EARLY_PRUNE") == nullptr;
-    if (early && args.join == 0 && args.op != 5) {
+    if (early && args.op != 5) {
       const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
-      int grid = grid_for_tiles(reinterpret_cast<const void*>(fle_pred32_early_kernel<32>), tiles);
+      auto kern = args.join != 0 ? fle_pred32_early_kernel<32, true> : fle_pred32_early_kernel<32, false>;
+      int grid = grid_for_tiles(reinterpret_cast<const void*>(kern), tiles);
       if (grid <= 0) return IPS_ERR_HIP;
-      hipLaunchKernelGGL(fle_pred32_early_kernel<32>, dim3(grid), dim3(kThreads), 0, s, enc, n_rows, args,
-                         bitmap32);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, s, enc, n_rows, args, bitmap32);
       IPS_HIP_TRY(hipGetLastError());
       return IPS_OK;
     }

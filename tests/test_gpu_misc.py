@@ -593,3 +593,27 @@ def test_plain_scan(capi, O, type_name):
         check(*capi.plain_scan(d_page, n, t, O.OP_IN, lst), np.isin(vals, lst))
     with pytest.raises(capi.IpsError):
         capi.plain_scan(d_page, n, t, O.OP_IN, lst, semantics=O.SEM_REFERENCE)
+
+
+def test_between_on_a_32_bit_column(capi, O):
+    """Two comparisons on one w=32 column in one pass (the early-pruning kernel's pair form):
+    constants that are present, rows that share the constants' high 16 bits (undecided after the
+    high planes), and sub-tiles with and without such rows."""
+    rng = np.random.default_rng(3232)
+    n = 9 * 2048 + 77
+    vals = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    lo, hi = np.uint32(0x40001234), np.uint32(0xC000BEEF)
+    vals[5000:5100] = (lo & np.uint32(0xFFFF0000)) | rng.integers(0, 1 << 16, 100).astype(np.uint32)
+    vals[12000:12003] = [lo, hi, hi]
+    vals[-3:] = (hi & np.uint32(0xFFFF0000)) | np.array([0, 0xBEEF, 0xFFFF], np.uint32)
+    enc = dev_words(O.fle_encode(vals, 32))
+    cols = [capi.fle_column(enc, 32)]
+    L, AND, OR = capi.leaf, capi.and_node, capi.or_node
+    for ops, joiner, truth in (
+            ((O.OP_GE, O.OP_LE), AND, (vals >= lo) & (vals <= hi)),
+            ((O.OP_GT, O.OP_LT), AND, (vals > lo) & (vals < hi)),
+            ((O.OP_LT, O.OP_GT), OR, (vals < lo) | (vals > hi)),
+            ((O.OP_EQ, O.OP_EQ), OR, (vals == lo) | (vals == hi))):
+        nodes = [L(0, ops[0], int(lo)), L(0, ops[1], int(hi)), joiner()]
+        got = bits_of(words(capi.eval_program(nodes, cols, n)), n)
+        assert np.array_equal(got, truth), ops
