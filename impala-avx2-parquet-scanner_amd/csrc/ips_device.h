@@ -122,6 +122,33 @@ __device__ __forceinline__ void tile_load(const uint64_t* __restrict__ enc, int6
   }
 }
 
+// Late materialisation against a given bitmap touches only the blocks that hold a selected row --
+// what FleDecoder::Get(val, skip) / Skip() do with pointer arithmetic (fle-encoding.h:344-402:
+// whole blocks are stepped over, never unpacked).  need_blocks: bit 2b set <-> block b of the
+// sub-tile is needed; lanes whose 16-byte chunk lies in unneeded blocks issue no load, so whole
+// cache lines of such blocks are never fetched.  Registers of skipped chunks keep stale data: it
+// only reaches lanes that have no selected row.
+template <int MAXLOADS, int W>
+__device__ __forceinline__ void tile_load_needed(const uint64_t* __restrict__ enc, int64_t tile,
+                                                 int64_t total_words, int lane,
+                                                 uint64_t need_blocks, u32x4 (&r)[MAXLOADS]) {
+  const int64_t w0 = tile * (int64_t)(kBlocksPerTile * W);
+  if (w0 + kBlocksPerTile * W > total_words) {  // last, partial sub-tile: the guarded plain path
+    tile_load<MAXLOADS, true>(enc, tile, W, total_words, lane, r);
+    return;
+  }
+  const uint64_t* base = enc + w0;
+#pragma unroll
+  for (int i = 0; i < MAXLOADS; ++i) {
+    const int c = i * kWave + lane;
+    if (c < 16 * W) {
+      const int b0 = (2 * c) / W, b1 = (2 * c + 1) / W;
+      if (((need_blocks >> (2 * b0)) | (need_blocks >> (2 * b1))) & 1ull)
+        r[i] = stream_load<true>(reinterpret_cast<const u32x4*>(base + 2 * c));
+    }
+  }
+}
+
 // ---- VGPR -> LDS (odd word stride per block) ------------------------------------------------
 // inv_w = floor(2^32 / w) + 1 when the caller has it (w changes at run time inside the kernel):
 // word / w == umulhi(word, inv_w) exactly for word < 2^16; 0 = divide.

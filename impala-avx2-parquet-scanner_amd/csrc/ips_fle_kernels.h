@@ -110,12 +110,48 @@ __device__ __forceinline__ void fle_scan_body(
   const int64_t bm_dwords = bitmap_dwords(n_rows);
   int64_t tile = first_tile;
 
+  // given bitmap: this lane's dword of the sub-tile, and which blocks hold a selected row
+  auto given_dword = [&](int64_t t) -> uint32_t {
+    const int64_t gd = t * 64 + lane;
+    return (t < tiles && gd < bm_dwords) ? given_bitmap32[gd] : 0u;
+  };
+  auto needed_blocks = [&](uint32_t g) -> uint64_t {
+    const uint64_t any = __builtin_amdgcn_ballot_w64(g != 0u);  // bit l <-> half-block of lane l
+    return any | (any >> 1);                                    // bit 2b <-> block b
+  };
   u32x4 r[L];
-  if (tile < tiles) tile_load<L>(enc, tile, W, total_words, lane, r);
+  for (int i = 0; i < L; ++i) r[i] = u32x4{0u, 0u, 0u, 0u};
+  uint32_t given_cur = 0u, given_nxt = 0u;
+  if (MODE == kScanGivenBitmap) {
+    given_cur = given_dword(tile);
+    given_nxt = given_dword(tile + stride);
+    if (tile < tiles) tile_load_needed<L, W>(enc, tile, total_words, lane, needed_blocks(given_cur), r);
+  } else if (tile < tiles) {
+    tile_load<L>(enc, tile, W, total_words, lane, r);
+  }
   while (tile < tiles) {
-    tile_to_lds<L>(lds32, W, lane, r);
     const int64_t next = tile + stride;
-    if (next < tiles) tile_load<L>(enc, next, W, total_words, lane, r);  // register prefetch
+    if (MODE == kScanGivenBitmap) {
+      // nothing selected in this sub-tile (nothing was loaded for it either): count 0, move on
+      const int64_t row0 = tile * kRowsPerTile + (int64_t)lane * 32;
+      const bool mine_live = given_cur != 0u && row0 < n_rows;
+      if (__builtin_amdgcn_ballot_w64(mine_live) == 0ull) {
+        if (next < tiles) tile_load_needed<L, W>(enc, next, total_words, lane, needed_blocks(given_nxt), r);
+        given_cur = given_nxt;
+        given_nxt = given_dword(next + stride);
+        if (lane == 0) batch_counts[tile] = 0u;
+        tile = next;
+        continue;
+      }
+    }
+    tile_to_lds<L>(lds32, W, lane, r);
+    uint32_t given_nn = 0u;
+    if (MODE == kScanGivenBitmap) {
+      if (next < tiles) tile_load_needed<L, W>(enc, next, total_words, lane, needed_blocks(given_nxt), r);
+      given_nn = given_dword(next + stride);  // bitmap prefetch, two sub-tiles ahead
+    } else if (next < tiles) {
+      tile_load<L>(enc, next, W, total_words, lane, r);  // register prefetch
+    }
     wave_lds_fence();
 
     const int64_t d = tile * 64 + lane;
@@ -140,9 +176,10 @@ __device__ __forceinline__ void fle_scan_body(
       bm = finish_bitmap_dword(pred_from_regs<W>(p, args), tile, lane, n_rows);
       if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, bm);
     } else if (MODE == kScanGivenBitmap) {
-      bm = d < bm_dwords ? given_bitmap32[d] : 0u;
-      bm = bitrev32(bm);  // finish_bitmap_dword reverses back; only the row mask is wanted
+      bm = bitrev32(given_cur);  // finish_bitmap_dword reverses back; only the row mask is wanted
       bm = finish_bitmap_dword(bm, tile, lane, n_rows);
+      given_cur = given_nxt;
+      given_nxt = given_nn;
     }
 
     uint32_t count = 0;
