@@ -33,7 +33,7 @@ constexpr int kThreads = kWave * kWavesPerBlock;
 struct PredArgs {
   int32_t op;        // ips_op
   int32_t n_consts;  // 1, or 1..256 for IN
-  // predicate-only kernels (used by the conjunct-chain strategy of ips_eval_program):
+  // predicate-only kernels (used by the per-operand plan of ips_eval_program):
   int32_t combine;   // 0: bitmap = result; 1: bitmap &= result; 2: bitmap |= result
   int32_t join;      // 0: single predicate; 1 / 2: result = pred(op, consts[0]) AND / OR
   int32_t op2;       //    pred(op2, const2), both evaluated in ONE pass over the planes

@@ -180,7 +180,7 @@ def test_nullable_dictionary_column(capi, O):
 def test_fused_program(capi, O, strategy, monkeypatch):
     """EvalSimplePredicates over several columns vs numpy: BETWEEN = And(Ge, Le); And(Gt a, Lt b);
     Or; IN; PLAIN leaves (int32, int64, double).  'auto' lets ips_eval_program use the
-    conjunct-chain strategy where the tree is a chain; 'general' forces the one-launch
+    per-operand plan (stand-alone predicate kernels on a stack of bitmaps); 'general' forces the one-launch
     program kernel for every tree."""
     if strategy == "general":
         monkeypatch.setenv("IPS_PROGRAM_NO_CHAIN", "1")
