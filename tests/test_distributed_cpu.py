@@ -40,6 +40,57 @@ def _worker(rank, world, port, n_rows, bw, ret):
     dist.destroy_process_group()
 
 
+def _worker_q6(rank, world, port, n_rows, ret):
+    """configs[4]: the three Q6 columns share the stripes; each rank ANDs its stripe's five leaf
+    bitmaps (the oracle stands in for ips_eval_program) and the stripes' words are all-gathered."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import __graft_entry__ as g
+    from oracle import oracle as O
+    pkg = g.load_package()
+    sharding, q6 = pkg.sharding, pkg.q6
+    ops = {"GE": O.OP_GE, "LT": O.OP_LT}
+    row0, row1 = sharding.stripe_bounds(n_rows, world, rank)
+    m = row1 - row0
+    local = np.zeros(0, np.uint64)
+    if m > 0:
+        # rank r materialises only ITS rows of every column (generated from the row offset)
+        encs = [O.fle_encode(q6.codes_numpy(c, m, start=row0), q6.COLUMNS[c][3]) for c in range(3)]
+        for col, op, k in q6.LEAVES:
+            leaf = O.fle_pred(encs[col], m, q6.COLUMNS[col][3], ops[op], k)
+            local = leaf if local.size == 0 else (local & leaf)
+    full = sharding.allgather_bitmap(torch.from_numpy(local.view(np.int64).copy()), n_rows, world)
+    codes = [q6.codes_numpy(c, n_rows) for c in range(3)]
+    exp = np.packbits(q6.truth(codes), bitorder="little")
+    exp = np.concatenate([exp, np.zeros((-len(exp)) % 8, np.uint8)]).view(np.uint64)
+    ok = np.array_equal(full.numpy().view(np.uint64), exp)
+    t = torch.tensor([int(ok)])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        ret.put(bool(t.item()))
+    dist.destroy_process_group()
+
+
+def _run_world(target, args, world=2):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world) + args + (ret,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return ret.get(timeout=10)
+
+
+@pytest.mark.parametrize("n_rows", [2048 * 5 + 77, 1500, 2048 * 4])
+def test_q6_three_column_conjunction_over_stripes(n_rows):
+    port = 31500 + (os.getpid() + n_rows) % 2000
+    assert _run_world(_worker_q6, (port, n_rows)) is True
+
+
 @pytest.mark.parametrize("n_rows,bw", [(10000, 12), (2048 * 7 + 5, 32), (100, 4), (2048 * 2, 9)])
 def test_allgather_of_stripe_bitmaps(n_rows, bw):
     world = 2

@@ -1,0 +1,108 @@
+"""BASELINE configs[4] on the HIP kernels: the TPC-H-Q6-shaped three-column conjunction
+(EvalSimplePredicates' conjunct AND, hdfs-parquet-scanner.cc:1857-1862) at the
+full 600,037,902 rows on one GPU, and row stripes cut by sharding.stripe_bounds, scanned one by
+one by the HIP kernels and concatenated, against the unsharded result."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def words(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def oracle_q6_bitmap(O, q6, n, start=0):
+    """The conjunction leaf by leaf through the oracle's FleDecoder predicates + AND."""
+    ops = {"GE": O.OP_GE, "LT": O.OP_LT}
+    encs = [O.fle_encode(q6.codes_numpy(c, n, start), q6.COLUMNS[c][3]) for c in range(3)]
+    bm = None
+    for col, op, k in q6.LEAVES:
+        leaf = O.fle_pred(encs[col], n, q6.COLUMNS[col][3], ops[op], k)
+        bm = leaf if bm is None else (bm & leaf)
+    return bm
+
+
+def pack_mask(mask):
+    """bool tensor -> LSB-first int64 bitmap words (zero padded), on the GPU."""
+    n = mask.numel()
+    pad = (-n) % 64
+    if pad:
+        mask = torch.cat([mask, torch.zeros(pad, dtype=torch.bool, device=mask.device)])
+    w = mask.view(-1, 64).to(torch.int64)
+    return (w << torch.arange(64, device=w.device, dtype=torch.int64)).sum(dim=1)
+
+
+def test_config4_q6_600m_rows_one_gpu(capi, ips, O):
+    q6 = ips.q6
+    n = q6.ROWS
+    codes = [q6.codes_gpu(capi, c, n) for c in range(3)]
+    encs = [capi.fle_encode(codes[c], q6.COLUMNS[c][3]) for c in range(3)]
+    nodes, cols = q6.program(capi, encs)
+    bm = capi.eval_program(nodes, cols, n)
+    mask = q6.truth(codes)
+    n_sel = int(mask.sum().item())
+    # 365/2526 * 3/11 * 23/50 = 1.81 % of the rows
+    assert abs(n_sel / n - (365 / 2526) * (3 / 11) * (23 / 50)) < 2e-4
+    assert capi.bitmap_count(bm, n) == n_sel
+    # every bit, against torch on the raw codes; the padding bits of the last word are zero
+    exp = pack_mask(mask)
+    assert torch.equal(exp, bm)
+    assert (int(bm[-1].item()) & 0xFFFFFFFFFFFFFFFF) >> (n % 64) == 0
+    del exp, mask
+    # oracle-exact on the first 2^20 rows
+    n1 = 1 << 20
+    assert np.array_equal(words(bm[:n1 // 64]), oracle_q6_bitmap(O, q6, n1))
+    # idempotence and the one-launch interpreter agree with the per-operand plan
+    assert torch.equal(capi.eval_program(nodes, cols, n), bm)
+    # the scan carried on: late materialisation of l_quantity's codes against the bitmap
+    bvals, counts = capi.fle_select(encs[2], n, 6, bm)
+    assert int(counts.to(torch.int64).sum().item()) == n_sel
+    dense = capi.batches_compact(bvals, counts, n)
+    sel_codes = torch.masked_select(codes[2], q6.truth(codes))
+    assert torch.equal(dense, sel_codes)
+    assert int(dense.max().item()) < 23
+
+
+@pytest.mark.parametrize("n", [2048 * 37 + 777, 3000, 2048 * 8, (1 << 22) + 12345])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_stripes_scanned_by_the_hip_kernels_concatenate(capi, ips, O, n, world):
+    """Cut the three columns with sharding.stripe_bounds for `world` ranks, run ips_eval_program
+    and the fused ips_fle_scan on every stripe with the HIP kernels, concatenate: the result is
+    the unsharded bitmap / batches (ragged last stripe, empty stripes included)."""
+    q6, sh = ips.q6, ips.sharding
+    codes = [q6.codes_gpu(capi, c, n) for c in range(3)]
+    encs = [capi.fle_encode(codes[c], q6.COLUMNS[c][3]) for c in range(3)]
+    nodes, cols = q6.program(capi, encs)
+    whole = capi.eval_program(nodes, cols, n)
+    w_bm, w_vals, w_cnt = capi.fle_scan(encs[0], n, 12, capi.OP_LT, 365)
+    assert np.array_equal(words(whole), oracle_q6_bitmap(O, q6, n))
+
+    s_rows = sh.stripe_rows(n, world)
+    assert s_rows % 2048 == 0
+    pieces, scan_pieces, cnt_pieces, val_pieces = [], [], [], []
+    for rank in range(world):
+        row0, row1 = sh.stripe_bounds(n, world, rank)
+        m = row1 - row0
+        if m == 0:  # ranks beyond the data hold an empty stripe
+            continue
+        senc = [sh.stripe_word_slice(encs[c], q6.COLUMNS[c][3], n, world, rank) for c in range(3)]
+        for c in range(3):
+            assert senc[c].data_ptr() % 16 == 0
+            assert senc[c].numel() == ((m + 63) // 64) * q6.COLUMNS[c][3]
+        snodes, scols = q6.program(capi, senc)
+        pieces.append(capi.eval_program(snodes, scols, m))
+        bm, vals, cnt = capi.fle_scan(senc[0], m, 12, capi.OP_LT, 365)
+        scan_pieces.append(bm)
+        cnt_pieces.append(cnt)
+        val_pieces.append(vals[:cnt.numel() * 2048])
+        # a stripe regenerated from its own row offset holds the same codes (what rank r would do)
+        assert torch.equal(q6.codes_gpu(capi, 0, min(m, 4096), start=row0), codes[0][row0:row0 + min(m, 4096)])
+    # every stripe but the last is a whole number of bitmap words and of batches
+    assert torch.equal(torch.cat(pieces), whole)
+    assert torch.equal(torch.cat(scan_pieces), w_bm)
+    assert torch.equal(torch.cat(cnt_pieces), w_cnt)
+    nb = w_cnt.numel()
+    assert torch.equal(capi.batches_compact(torch.cat(val_pieces), torch.cat(cnt_pieces), n),
+                       capi.batches_compact(w_vals[:nb * 2048], w_cnt, n))
