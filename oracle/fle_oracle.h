@@ -127,6 +127,12 @@ int64_t orc_fle_select(const uint64_t* enc, int64_t enc_bytes, int64_t n, int bw
  * mode 1 = reference-shaped 1024-row batches.  Returns selected-row count. */
 int64_t orc_bench_fused(const uint64_t* enc, int64_t n, int bw, int op, uint64_t value,
                         int threads, int mode, uint64_t* bitmap, uint32_t* sel_out);
+/* best-of-reps seconds of orc_bench_fused after a warm-up pass, buffers pre-touched by the caller */
+double orc_bench_fused_best(const uint64_t* enc, int64_t n, int bw, int op, uint64_t value,
+                            int threads, int mode, uint64_t* bitmap, uint32_t* sel_out, int reps,
+                            int64_t* n_sel);
+void orc_fast_unpack_block(const uint64_t* blk, int bw, uint32_t* out64);
+void orc_swar_unpack_block(const uint64_t* blk, int bw, uint32_t* out64);
 int orc_hw_threads(void);
 int orc_has_avx2(void);
 

@@ -49,6 +49,7 @@ def lib():
         _lib.orc_skip_list.restype = C.c_int64
         _lib.orc_fle_select.restype = C.c_int64
         _lib.orc_bench_fused.restype = C.c_int64
+        _lib.orc_bench_fused_best.restype = C.c_double
     return _lib
 
 
@@ -278,6 +279,27 @@ def bench_fused(enc, n, bw, op, value, threads, mode=0):
                                 C.c_uint64(value), C.c_int(threads), C.c_int(mode), _p(bitmap),
                                 _p(sel))
     return int(cnt), bitmap, sel
+
+
+def bench_buffers(n):
+    """Output buffers of the timed baseline, allocated and touched ONCE by the caller: a fresh
+    np.empty(n) per run would add a page fault per 4 KiB of output to every timed call."""
+    bitmap = np.zeros((n + 63) // 64, dtype=np.uint64)
+    sel = np.zeros(n, dtype=np.uint32)
+    return bitmap, sel
+
+
+def bench_fused_best(enc, n, bw, op, value, threads, mode, buffers, reps=5):
+    """Best-of-reps seconds of the baseline body, timed inside C after one warm-up pass.
+    -> (seconds, n_selected)"""
+    enc = np.ascontiguousarray(enc, dtype=np.uint64)
+    bitmap, sel = buffers
+    assert len(bitmap) >= (n + 63) // 64 and len(sel) >= n
+    cnt = C.c_int64(0)
+    sec = lib().orc_bench_fused_best(_p(enc), C.c_int64(n), C.c_int(bw), C.c_int(op),
+                                     C.c_uint64(value), C.c_int(threads), C.c_int(mode),
+                                     _p(bitmap), _p(sel), C.c_int(reps), C.byref(cnt))
+    return float(sec), int(cnt.value)
 
 
 def hw_threads():
