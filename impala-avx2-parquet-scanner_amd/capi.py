@@ -39,6 +39,7 @@ SYMBOLS = [
     "ips_fle_select", "ips_fle_scan_pages", "ips_batches_workspace_bytes", "ips_batches_compact", "ips_assemble_tuples",
     "ips_assemble_workspace_bytes", "ips_bitmap_compress",
     "ips_dict_open", "ips_dict_close", "ips_dict_num_entries", "ips_dict_bit_width", "ips_dict_encode",
+    "ips_dict_encode_workspace_bytes", "ips_program_workspace_bytes",
     "ips_dict_translate", "ips_dict_pred", "ips_dict_decode", "ips_dict_scan", "ips_dict_select",
     "ips_plain_stride", "ips_plain_pred", "ips_plain_scan", "ips_plain_select",
     "ips_bitmap_and", "ips_bitmap_or", "ips_bitmap_fill", "ips_bitmap_count",
@@ -89,7 +90,10 @@ def lib():
         L.ips_dict_num_entries.restype = C.c_int64
         L.ips_dict_num_entries.argtypes = [C.c_void_p]
         L.ips_dict_bit_width.argtypes = [C.c_int64]
-        for name in ("ips_batches_workspace_bytes", "ips_expand_workspace_bytes"):
+        L.ips_program_workspace_bytes.restype = C.c_size_t
+        L.ips_program_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int64]
+        for name in ("ips_batches_workspace_bytes", "ips_expand_workspace_bytes",
+                     "ips_dict_encode_workspace_bytes"):
             getattr(L, name).restype = C.c_size_t
             getattr(L, name).argtypes = [C.c_int64]
         _lib = L
@@ -350,9 +354,11 @@ def dict_encode(values, type_, stream=None):
     dict_len = C.c_int64(0)
     bw = C.c_int(0)
     enc = torch.empty(max(fle_encoded_bytes(n, 16) // 8, 2), dtype=torch.int64, device=values.device)
+    ws = torch.empty(int(lib().ips_dict_encode_workspace_bytes(n)), dtype=torch.uint8,
+                     device=values.device)
     _ck(lib().ips_dict_encode(_ptr(values), C.c_int64(n), type_, page.ctypes.data_as(C.c_void_p),
                               C.c_int64(len(page)), C.byref(dict_len), C.byref(bw), _ptr(enc),
-                              _stream(stream)))
+                              _ptr(ws), _stream(stream)))
     return page[:dict_len.value].copy(), bw.value, enc[:fle_encoded_bytes(n, bw.value) // 8]
 
 
@@ -482,14 +488,25 @@ def plain_column(page, type_):
     return c
 
 
-def eval_program(nodes, cols, n_rows, bitmap=None, device=None, stream=None):
+def program_workspace_bytes(nodes, n_rows):
+    arr_n = (Node * len(nodes))(*nodes)
+    return int(lib().ips_program_workspace_bytes(arr_n, len(nodes), n_rows))
+
+
+def eval_program(nodes, cols, n_rows, bitmap=None, device=None, stream=None, workspace=None):
+    """workspace: uint8 tensor of program_workspace_bytes() bytes (allocated here when the tree
+    needs one and none is given; pass it to keep the call allocation-free, e.g. under capture)."""
     arr_n = (Node * len(nodes))(*nodes)
     arr_c = (Column * len(cols))(*cols)
+    device = device or (bitmap.device if bitmap is not None else torch.device("cuda"))
     if bitmap is None:
-        bitmap = torch.empty(max(_words(n_rows), 2), dtype=torch.int64,
-                             device=device or torch.device("cuda"))
+        bitmap = torch.empty(max(_words(n_rows), 2), dtype=torch.int64, device=device)
+    if workspace is None:
+        need = int(lib().ips_program_workspace_bytes(arr_n, len(nodes), n_rows))
+        if need:
+            workspace = torch.empty(need, dtype=torch.uint8, device=device)
     _ck(lib().ips_eval_program(arr_n, len(nodes), arr_c, len(cols), C.c_int64(n_rows),
-                               _ptr(bitmap), _stream(stream)))
+                               _ptr(bitmap), _ptr(workspace), _stream(stream)))
     return bitmap[:_words(n_rows)]
 
 

@@ -484,6 +484,8 @@ static void translate_t(const ips_dict* d, ips_op op, const void* literals, int 
   *fle_op = op;
   if (d->n == 0) { *kind = IPS_XL_ALL_FALSE; return; }
   const T v = lit[0];
+  // a NaN literal compares false with everything (IEEE); it must not reach lower_bound either
+  if (op != IPS_OP_IN && v != v) { *kind = IPS_XL_ALL_FALSE; return; }
   switch (op) {
     case IPS_OP_EQ: {
       const T* it = std::lower_bound(first, last, v);
@@ -517,6 +519,7 @@ static void translate_t(const ips_dict* d, ips_op op, const void* literals, int 
       return;
     default: {
       for (int i = 0; i < n_literals; ++i) {
+        if (lit[i] != lit[i]) continue;  // NaN
         const T* it = std::lower_bound(first, last, lit[i]);
         if (it == last || lit[i] < *it) continue;
         codes[(*n_codes)++] = (uint64_t)(it - first);
@@ -576,6 +579,18 @@ ips_status ips_dict_open(const void* h_dict_page, int64_t dict_len, ips_type typ
     if (type == IPS_T_INT8) { int32_t x = *(int8_t*)&d->host[(size_t)i]; memcpy(&dev[(size_t)i * 4], &x, 4); }
     else if (type == IPS_T_INT16) { int16_t h; memcpy(&h, &d->host[(size_t)i * 2], 2); int32_t x = h; memcpy(&dev[(size_t)i * 4], &x, 4); }
     else memcpy(&dev[(size_t)i * slot], page + i * slot, (size_t)slot);
+  }
+  // the literal translation binary-searches with T's operator<: the page must be ascending, which
+  // rules out NaN entries (no strict weak order)
+  bool ordered = true;
+  for (int64_t i = 0; i < d->n && ordered; ++i) {
+    if (type == IPS_T_FLOAT) { float x; memcpy(&x, &d->host[(size_t)i * 4], 4); ordered = x == x; }
+    else if (type == IPS_T_DOUBLE) { double x; memcpy(&x, &d->host[(size_t)i * 8], 8); ordered = x == x; }
+  }
+  if (!ordered) {
+    delete d;
+    set_error("ips_dict_open: NaN entry in a FLOAT/DOUBLE dictionary (order undefined, dict-encoding.h:370-372)");
+    return IPS_ERR_INVALID_ARG;
   }
   hipError_t e = hipMalloc(&d->d_entries, dev.size() ? dev.size() : 16);
   if (e != hipSuccess) { delete d; return hip_fail(e, "hipMalloc(dictionary)"); }

@@ -144,29 +144,37 @@ static T from_bits(uint64_t bits) {
   return t;
 }
 
+template <typename T>
+static bool is_nan(T) { return false; }
+template <>
+bool is_nan<float>(float v) { return v != v; }
+template <>
+bool is_nan<double>(double v) { return v != v; }
+
+// Workspace layout (all temporaries come from the caller: the entry point allocates and frees
+// nothing): hash table | code of every slot | counters | one 4-byte code per row.
+static size_t ws_table_off() { return 0; }
+static size_t ws_code_of_slot_off() { return (size_t)kTableSlots * 8; }
+static size_t ws_counters_off() { return ws_code_of_slot_off() + (size_t)kTableSlots * 4; }
+static size_t ws_codes_off() { return ws_counters_off() + 256; }
+size_t dict_encode_workspace_bytes(int64_t n_rows) {
+  return ws_codes_off() + (size_t)(n_rows > 0 ? n_rows : 1) * 4 + 16;
+}
+
 template <typename T, typename S>
 static ips_status dict_encode_t(const void* d_values, int64_t n, ips_type type, void* h_dict_page,
                                 int64_t page_capacity, int64_t* dict_len, int* bit_width,
-                                void* d_codes_enc, hipStream_t s) {
-  unsigned long long* d_table = nullptr;
-  unsigned int* d_counters = nullptr;
-  uint32_t* d_code_of_slot = nullptr;
-  uint32_t* d_codes = nullptr;
-  auto cleanup = [&]() {
-    if (d_table) (void)hipFree(d_table);
-    if (d_counters) (void)hipFree(d_counters);
-    if (d_code_of_slot) (void)hipFree(d_code_of_slot);
-    if (d_codes) (void)hipFree(d_codes);
-  };
+                                void* d_codes_enc, void* d_workspace, hipStream_t s) {
+  uint8_t* ws = reinterpret_cast<uint8_t*>(d_workspace);
+  unsigned long long* d_table = reinterpret_cast<unsigned long long*>(ws + ws_table_off());
+  unsigned int* d_counters = reinterpret_cast<unsigned int*>(ws + ws_counters_off());
+  uint32_t* d_code_of_slot = reinterpret_cast<uint32_t*>(ws + ws_code_of_slot_off());
+  uint32_t* d_codes = reinterpret_cast<uint32_t*>(ws + ws_codes_off());
 #define IPS_TRY_CLEAN(expr)                                     \
   do {                                                          \
     hipError_t _e = (expr);                                     \
-    if (_e != hipSuccess) { cleanup(); return hip_fail(_e, #expr); } \
+    if (_e != hipSuccess) return hip_fail(_e, #expr);              \
   } while (0)
-  IPS_TRY_CLEAN(hipMalloc(&d_table, (size_t)kTableSlots * 8));
-  IPS_TRY_CLEAN(hipMalloc(&d_counters, 8));
-  IPS_TRY_CLEAN(hipMalloc(&d_code_of_slot, (size_t)kTableSlots * 4));
-  IPS_TRY_CLEAN(hipMalloc(&d_codes, (size_t)(n > 0 ? n : 1) * 4 + 16));
   IPS_TRY_CLEAN(hipMemsetAsync(d_table, 0xFF, (size_t)kTableSlots * 8, s));
   IPS_TRY_CLEAN(hipMemsetAsync(d_counters, 0, 8, s));
   const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_cus() * 8);
@@ -178,13 +186,11 @@ static ips_status dict_encode_t(const void* d_values, int64_t n, ips_type type, 
   IPS_TRY_CLEAN(hipStreamSynchronize(s));
   const int64_t entries = (int64_t)counters[0] + (counters[1] ? 1 : 0);
   if (entries > kMaxEntries) {
-    cleanup();
     set_error("ips_dict_encode: more than %d distinct values (dict-encoding.h:157): use PLAIN", kMaxEntries);
     return IPS_ERR_UNSUPPORTED;
   }
   const int slot = ips_plain_stride(type);
   if (entries * slot > page_capacity) {
-    cleanup();
     set_error("ips_dict_encode: dictionary page needs %lld bytes", (long long)(entries * slot));
     return IPS_ERR_INVALID_ARG;
   }
@@ -196,6 +202,15 @@ static ips_status dict_encode_t(const void* d_values, int64_t n, ips_type type, 
   for (uint32_t h = 0; h < kTableSlots; ++h)
     if (table[h] != kEmpty) ents.push_back(Entry{from_bits<T>(table[h]), h});
   if (counters[1]) ents.push_back(Entry{from_bits<T>(kEmpty), kTableSlots});
+  // operator< is not a strict weak order once a NaN is present (std::sort / lower_bound would be
+  // undefined behaviour): such a column is not dictionary-encoded here
+  for (const Entry& e : ents) {
+    if (is_nan<T>(e.value)) {
+      set_error("ips_dict_encode: NaN in a FLOAT/DOUBLE column: dictionary order undefined "
+                "(dict-encoding.h:370-372), use PLAIN");
+      return IPS_ERR_UNSUPPORTED;
+    }
+  }
   std::sort(ents.begin(), ents.end(), [](const Entry& a, const Entry& b) { return a.value < b.value; });
   std::vector<uint32_t> code_of_slot(kTableSlots, 0);
   uint32_t code_of_ones = 0;
@@ -220,7 +235,6 @@ static ips_status dict_encode_t(const void* d_values, int64_t n, ips_type type, 
     st = launch_fle_encode(bw, 4, d_codes, n, reinterpret_cast<uint64_t*>(d_codes_enc), s);
     IPS_TRY_CLEAN(hipStreamSynchronize(s));
   }
-  cleanup();
   return st;
 #undef IPS_TRY_CLEAN
 }
@@ -229,22 +243,28 @@ static ips_status dict_encode_t(const void* d_values, int64_t n, ips_type type, 
 
 using namespace ips;
 
+extern "C" size_t ips_dict_encode_workspace_bytes(int64_t n_rows) {
+  return dict_encode_workspace_bytes(n_rows);
+}
+
 extern "C" ips_status ips_dict_encode(const void* d_values, int64_t n_rows, ips_type type,
                                       void* h_dict_page, int64_t dict_page_capacity,
                                       int64_t* dict_len, int* bit_width, void* d_codes_enc,
-                                      ips_stream stream) {
+                                      void* d_workspace, ips_stream stream) {
   IPS_REQUIRE(n_rows >= 0, "ips_dict_encode: n_rows < 0");
   IPS_REQUIRE(type >= IPS_T_INT8 && type <= IPS_T_DOUBLE, "ips_dict_encode: bad type %d", (int)type);
   IPS_REQUIRE(h_dict_page && dict_len && bit_width, "ips_dict_encode: NULL out pointer");
   IPS_REQUIRE(n_rows == 0 || (d_values && aligned16(d_values) && d_codes_enc && aligned16(d_codes_enc)),
               "ips_dict_encode: NULL or misaligned device pointer");
+  IPS_REQUIRE(d_workspace && aligned16(d_workspace),
+              "ips_dict_encode: pass a workspace of ips_dict_encode_workspace_bytes() bytes");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (type) {
-    case IPS_T_INT8: return dict_encode_t<int8_t, int32_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, s);
-    case IPS_T_INT16: return dict_encode_t<int16_t, int32_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, s);
-    case IPS_T_INT32: return dict_encode_t<int32_t, int32_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, s);
-    case IPS_T_INT64: return dict_encode_t<int64_t, int64_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, s);
-    case IPS_T_FLOAT: return dict_encode_t<float, int32_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, s);
-    default: return dict_encode_t<double, int64_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, s);
+    case IPS_T_INT8: return dict_encode_t<int8_t, int32_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, d_workspace, s);
+    case IPS_T_INT16: return dict_encode_t<int16_t, int32_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, d_workspace, s);
+    case IPS_T_INT32: return dict_encode_t<int32_t, int32_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, d_workspace, s);
+    case IPS_T_INT64: return dict_encode_t<int64_t, int64_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, d_workspace, s);
+    case IPS_T_FLOAT: return dict_encode_t<float, int32_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, d_workspace, s);
+    default: return dict_encode_t<double, int64_t>(d_values, n_rows, type, h_dict_page, dict_page_capacity, dict_len, bit_width, d_codes_enc, d_workspace, s);
   }
 }

@@ -408,53 +408,29 @@ ips_status emit_item(const ChainItem& it, int combine, const ips_column* cols, i
 // Plans the whole tree on a stack of bitmaps.  Operands are folded into an existing bitmap
 // whenever one side of an AND / OR already is one (both commute); two leaf operands open a new
 // bitmap; two bitmaps are merged by ips_bitmap_and / or's kernel.  The bitmap the root ends up in
-// is mapped onto d_bitmap, the others (a left-deep conjunct chain has none) live in the stream's
-// scratch buffer (plan_scratch).
-// Temporary bitmaps of a plan: one grow-only buffer per (device, stream), plain hipMalloc memory
-// like every other buffer the kernels touch.  Work on a stream is ordered, so consecutive calls
-// on one stream may share it; growing it frees the old one with hipFree, which waits for the
-// device first.  (The stream-ordered allocator was tried: its pool memory aborted a torch-free
-// host process in ips_dict_encode and is kept out of the product path.)  The first call that
-// needs temporaries on a stream therefore allocates; while that stream is being captured into a
-// hipGraph no allocation is allowed, *out stays NULL and the caller takes the one-launch kernel.
-ips_status plan_scratch(hipStream_t s, size_t bytes, uint8_t** out) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, std::pair<void*, size_t>> cache;
-  int dev = 0;
-  IPS_HIP_TRY(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(mu);
-  auto& e = cache[std::make_pair(dev, s)];
-  *out = nullptr;
-  if (e.second < bytes) {
-    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone)
-      return IPS_OK;
-    if (e.first) IPS_HIP_TRY(hipFree(e.first));
-    e.first = nullptr;
-    e.second = 0;
-    IPS_HIP_TRY(hipMalloc(&e.first, bytes));
-    e.second = bytes;
-  }
-  *out = reinterpret_cast<uint8_t*>(e.first);
-  return IPS_OK;
-}
+// is mapped onto d_bitmap, the others (a left-deep conjunct chain has none) live in the CALLER's
+// workspace (ips_program_workspace_bytes): the entry point allocates nothing, frees nothing and
+// never synchronises, so it can be captured into a hipGraph like every other launch.
+struct Item { int slot; const ips_node* a; const ips_node* b; int join; };  // slot < 0: leaf / pair
+struct Step { int kind; Item item; int combine; int dst; int src; };         // 0 pred, 1 merge
+struct Plan {
+  Step steps[2 * IPS_PROGRAM_MAX_NODES];
+  int n_steps = 0;
+  int n_slots = 0;
+  int root = 0;
+};
 
-// returns IPS_OK and *handled = true when the plan has been launched
-ips_status try_chain(const ips_node* nodes, int n_nodes, const ips_column* cols, int64_t n_rows,
-                     uint64_t* d_bitmap, hipStream_t s, bool* handled) {
-  *handled = false;
-  struct Item { int slot; const ips_node* a; const ips_node* b; int join; };  // slot < 0: leaf / pair
-  struct Step { int kind; Item item; int combine; int dst; int src; };         // 0 pred, 1 merge
-  Step plan[2 * IPS_PROGRAM_MAX_NODES];
-  int n_plan = 0, n_slots = 0;
+bool make_plan(const ips_node* nodes, int n_nodes, Plan* pl) {
   Item stack[IPS_PROGRAM_MAX_NODES];
   int sp = 0;
   for (int i = 0; i < n_nodes; ++i) {
     const ips_node& nd = nodes[i];
     if (nd.kind == IPS_NODE_LEAF) {
+      if (sp >= IPS_PROGRAM_MAX_NODES) return false;
       stack[sp++] = Item{-1, &nd, nullptr, 0};
       continue;
     }
+    if (sp < 2) return false;
     const int op = nd.kind == IPS_NODE_AND ? 1 : 2;
     Item y = stack[--sp];
     Item x = stack[--sp];
@@ -462,53 +438,61 @@ ips_status try_chain(const ips_node* nodes, int n_nodes, const ips_column* cols,
         x.a->op != IPS_OP_IN && y.a->op != IPS_OP_IN) {
       stack[sp++] = Item{-1, x.a, y.a, op};  // two leaves on one column: one pass
     } else if (x.slot >= 0 && y.slot >= 0) {
-      plan[n_plan++] = Step{1, Item{}, op, x.slot, y.slot};
+      pl->steps[pl->n_steps++] = Step{1, Item{}, op, x.slot, y.slot};
       stack[sp++] = x;
     } else if (x.slot >= 0 || y.slot >= 0) {
       const Item& bm = x.slot >= 0 ? x : y;
-      plan[n_plan++] = Step{0, x.slot >= 0 ? y : x, op, bm.slot, -1};
+      pl->steps[pl->n_steps++] = Step{0, x.slot >= 0 ? y : x, op, bm.slot, -1};
       stack[sp++] = bm;
     } else {
-      const int slot = n_slots++;
-      plan[n_plan++] = Step{0, x, 0, slot, -1};
-      plan[n_plan++] = Step{0, y, op, slot, -1};
+      const int slot = pl->n_slots++;
+      pl->steps[pl->n_steps++] = Step{0, x, 0, slot, -1};
+      pl->steps[pl->n_steps++] = Step{0, y, op, slot, -1};
       stack[sp++] = Item{slot, nullptr, nullptr, 0};
     }
   }
-  if (sp != 1) return IPS_OK;
+  if (sp != 1) return false;
   if (stack[0].slot < 0) {
-    plan[n_plan++] = Step{0, stack[0], 0, n_slots, -1};
-    stack[0].slot = n_slots++;
+    pl->steps[pl->n_steps++] = Step{0, stack[0], 0, pl->n_slots, -1};
+    stack[0].slot = pl->n_slots++;
   }
-  const int root = stack[0].slot;
+  pl->root = stack[0].slot;
+  return true;
+}
+
+size_t plan_slot_bytes(int64_t n_rows) {
   const size_t bitmap_bytes = (size_t)((n_rows + 63) / 64) * 8;
-  const size_t slot_bytes = (bitmap_bytes + 255) & ~(size_t)255;
-  uint8_t* temp = nullptr;
-  if (n_slots > 1) {
-    ips_status sst = plan_scratch(s, slot_bytes * (size_t)(n_slots - 1), &temp);
-    if (sst != IPS_OK) return sst;
-    if (!temp) return IPS_OK;  // capturing without scratch: not handled here
-  }
+  return (bitmap_bytes + 255) & ~(size_t)255;
+}
+
+ips_status run_plan(const Plan& pl, const ips_column* cols, int64_t n_rows, uint64_t* d_bitmap,
+                    uint8_t* temp, hipStream_t s) {
+  const size_t slot_bytes = plan_slot_bytes(n_rows);
   auto slot_ptr = [&](int slot) -> uint64_t* {
-    if (slot == root) return d_bitmap;
-    return reinterpret_cast<uint64_t*>(temp + slot_bytes * (size_t)(slot < root ? slot : slot - 1));
+    if (slot == pl.root) return d_bitmap;
+    return reinterpret_cast<uint64_t*>(temp + slot_bytes * (size_t)(slot < pl.root ? slot : slot - 1));
   };
   ips_status st = IPS_OK;
-  for (int i = 0; i < n_plan && st == IPS_OK; ++i) {
-    const Step& p = plan[i];
+  for (int i = 0; i < pl.n_steps && st == IPS_OK; ++i) {
+    const Step& p = pl.steps[i];
     if (p.kind == 0) st = emit_item(ChainItem{false, p.item.a, p.item.b, p.item.join}, p.combine, cols, n_rows, slot_ptr(p.dst), s);
     else st = launch_bitmap_binop(p.combine == 1 ? 0 : 1, slot_ptr(p.dst), slot_ptr(p.src), (n_rows + 63) / 64, s);
   }
-  if (st != IPS_OK) return st;
-  *handled = true;
-  return IPS_OK;
+  return st;
 }
 
 }  // namespace
 
+extern "C" size_t ips_program_workspace_bytes(const ips_node* nodes, int n_nodes, int64_t n_rows) {
+  if (!nodes || n_nodes < 1 || n_nodes > IPS_PROGRAM_MAX_NODES || n_rows <= 0) return 0;
+  Plan pl;
+  if (!make_plan(nodes, n_nodes, &pl) || pl.n_slots <= 1) return 0;
+  return plan_slot_bytes(n_rows) * (size_t)(pl.n_slots - 1);
+}
+
 extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const ips_column* cols,
                                        int n_cols, int64_t n_rows, uint64_t* d_bitmap,
-                                       ips_stream stream) {
+                                       void* d_workspace, ips_stream stream) {
   IPS_REQUIRE(nodes && n_nodes >= 1 && n_nodes <= IPS_PROGRAM_MAX_NODES,
               "ips_eval_program: n_nodes %d not in 1..%d", n_nodes, IPS_PROGRAM_MAX_NODES);
   IPS_REQUIRE(cols && n_cols >= 1 && n_cols <= IPS_PROGRAM_MAX_COLS,
@@ -587,11 +571,15 @@ extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const
   IPS_REQUIRE(depth == 1, "ips_eval_program: program leaves %d bitmaps on the stack", depth);
   IPS_REQUIRE(max_depth <= kStackDepth, "ips_eval_program: tree deeper than %d", kStackDepth);
   if (n_rows == 0) return IPS_OK;
-  if (getenv("IPS_PROGRAM_NO_CHAIN") == nullptr) {  // dev knob: force the general kernel
-    bool handled = false;
-    ips_status st = try_chain(nodes, n_nodes, cols, n_rows, d_bitmap,
-                              reinterpret_cast<hipStream_t>(stream), &handled);
-    if (st != IPS_OK || handled) return st;
+  if (getenv("IPS_PROGRAM_NO_CHAIN") == nullptr) {  // dev knob: force the one-launch kernel
+    Plan pl;
+    if (make_plan(nodes, n_nodes, &pl)) {
+      IPS_REQUIRE(pl.n_slots <= 1 || (d_workspace && aligned16(d_workspace)),
+                  "ips_eval_program: this tree keeps %d bitmaps alive: pass a workspace of "
+                  "ips_program_workspace_bytes() bytes", pl.n_slots);
+      return run_plan(pl, cols, n_rows, d_bitmap, reinterpret_cast<uint8_t*>(d_workspace),
+                      reinterpret_cast<hipStream_t>(stream));
+    }
   }
   return launch_program(prog, n_rows, reinterpret_cast<uint32_t*>(d_bitmap),
                         reinterpret_cast<hipStream_t>(stream));

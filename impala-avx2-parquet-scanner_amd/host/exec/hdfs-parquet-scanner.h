@@ -306,8 +306,13 @@ class HdfsParquetScanner {
     }
     bitmap_words->assign((size_t)((num_rows + 63) / 64), 0);
     ips::DeviceBuffer bm(bitmap_words->size() * 8);
+    // temporaries of trees that keep several bitmaps alive come from the caller (no hidden
+    // allocation inside the library); kept across calls
+    const size_t ws_bytes = ips_program_workspace_bytes(program.data(), (int)program.size(), num_rows);
+    if (ws_bytes > 0 && !program_workspace_.resize(ws_bytes)) return false;
     return ips::ok(ips_eval_program(program.data(), (int)program.size(), lower_cols_.data(),
-                                    (int)lower_cols_.size(), num_rows, bm.as<uint64_t>(), nullptr),
+                                    (int)lower_cols_.size(), num_rows, bm.as<uint64_t>(),
+                                    ws_bytes ? program_workspace_.get() : nullptr, nullptr),
                    "ips_eval_program") &&
            bm.download(bitmap_words->data(), bitmap_words->size() * 8);
   }
@@ -336,6 +341,7 @@ class HdfsParquetScanner {
   std::vector<SimplePredicate*> simple_predicates_;
   std::vector<SimplePredicate*> owned_;
   std::vector<ips_column> lower_cols_;
+  ips::DeviceBuffer program_workspace_;
 };
 
 // ---- ColumnReader dispatch helpers ----

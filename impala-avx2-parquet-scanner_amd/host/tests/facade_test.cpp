@@ -488,9 +488,13 @@ static void TestProgramWithTemporaryBitmap() {
                      inner(IPS_NODE_AND), inner(IPS_NODE_AND), inner(IPS_NODE_OR)};
   const int64_t words = (n + 63) / 64;
   ips::DeviceBuffer bm((size_t)words * 8);
+  const int n_prog = (int)(sizeof(prog) / sizeof(prog[0]));
+  const size_t ws_bytes = ips_program_workspace_bytes(prog, n_prog, n);
+  CHECK(ws_bytes >= (size_t)words * 8);  // (A and B) or (C and D) or ...: two bitmaps alive
+  CHECK(ips_eval_program(prog, n_prog, cols, 2, n, bm.as<uint64_t>(), nullptr, nullptr) == IPS_ERR_INVALID_ARG);
+  ips::DeviceBuffer ws(ws_bytes);
   for (int rep = 0; rep < 3; ++rep) {
-    CHECK(ips_eval_program(prog, (int)(sizeof(prog) / sizeof(prog[0])), cols, 2, n,
-                           bm.as<uint64_t>(), nullptr) == IPS_OK);
+    CHECK(ips_eval_program(prog, n_prog, cols, 2, n, bm.as<uint64_t>(), ws.get(), nullptr) == IPS_OK);
     std::vector<uint64_t> h((size_t)words);
     CHECK(bm.download(h.data(), (size_t)words * 8));
     int bad = 0, first_bad = -1;

@@ -99,10 +99,11 @@ class DictEncoder : public DictEncoderBase {
     const ips_type type = IpsTypeOf<T>::value;
     dict_page->assign((size_t)40000 * (size_t)ips_plain_stride(type), 0);
     ips::DeviceBuffer blocks((size_t)ips_fle_encoded_bytes(n, 16) + 16);
+    ips::DeviceBuffer workspace(ips_dict_encode_workspace_bytes(n));
     int64_t dict_len = 0;
     int bw = 0;
     const ips_status st = ips_dict_encode(d_values, n, type, dict_page->data(), (int64_t)dict_page->size(),
-                                          &dict_len, &bw, blocks.get(), stream);
+                                          &dict_len, &bw, blocks.get(), workspace.get(), stream);
     if (st == IPS_ERR_UNSUPPORTED) return false;
     if (!ips::ok(st, "ips_dict_encode")) return false;
     dict_page->resize((size_t)dict_len);

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IPS_VERSION 100 /* 0.1.0 */
+#define IPS_VERSION 200 /* 0.2.0: caller workspaces for ips_eval_program / ips_dict_encode, nullable leaves */
 
 typedef enum {
   IPS_OK = 0,
@@ -208,10 +208,14 @@ int ips_dict_bit_width(int64_t num_entries);
  * distinct values (dict-encoding.h:157) -> IPS_ERR_UNSUPPORTED, the caller falls back to PLAIN
  * like the reference's writer.  Synchronous (the <= 40000 entries are sorted on the host).
  * int8/int16 values are the low 1/2 bytes of their slot (what Decode reads) and are written to
- * the page sign-extended to int32; floats are keyed by bit pattern (+0.0 and -0.0 are two entries). */
+ * the page sign-extended to int32; floats are keyed by bit pattern (+0.0 and -0.0 are two entries);
+ * a NaN in a FLOAT/DOUBLE column -> IPS_ERR_UNSUPPORTED (operator< gives the dictionary no order,
+ * dict-encoding.h:370-372: fall back to PLAIN).  All temporaries live in d_workspace
+ * (ips_dict_encode_workspace_bytes(n_rows) bytes, 16-byte aligned): nothing is allocated. */
+size_t ips_dict_encode_workspace_bytes(int64_t n_rows);
 ips_status ips_dict_encode(const void* d_values, int64_t n_rows, ips_type type, void* h_dict_page,
                            int64_t dict_page_capacity, int64_t* dict_len, int* bit_width,
-                           void* d_codes_enc, ips_stream stream);
+                           void* d_codes_enc, void* d_workspace, ips_stream stream);
 
 /* Literal -> code translation of DictDecoder<T>::Eq/Lt/Le/Gt/Ge/In, dict-encoding.h:461-541.
  * literals: n_literals values of the dictionary's type (host).  codes must hold n_literals. */
@@ -326,12 +330,14 @@ typedef struct {
 
 #define IPS_PROGRAM_MAX_NODES 32
 #define IPS_PROGRAM_MAX_COLS 8
-/* Trees that keep more than one bitmap alive (an OR of ANDs) use a scratch buffer the library keeps
- * per (device, stream); the first such call on a stream allocates it.  While the stream is being
- * captured into a hipGraph and no scratch exists yet, the one-launch interpreter kernel is used
- * instead (same result, no allocation). */
+/* Trees that keep more than one bitmap alive (an OR of ANDs) park the extra bitmaps in d_workspace:
+ * ips_program_workspace_bytes(nodes, n_nodes, n_rows) bytes, 16-byte aligned; 0 for a conjunct
+ * chain, and then d_workspace may be NULL.  The call allocates nothing and only launches, so it
+ * can be captured into a hipGraph together with its workspace. */
+size_t ips_program_workspace_bytes(const ips_node* nodes, int n_nodes, int64_t n_rows);
 ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const ips_column* cols, int n_cols,
-                            int64_t n_rows, uint64_t* d_bitmap, ips_stream stream);
+                            int64_t n_rows, uint64_t* d_bitmap, void* d_workspace,
+                            ips_stream stream);
 
 /* ---- multi-GPU exchange (one process per GPU) ------------------------------------------------ */
 /* The path shards by row stripes (blocks of 64 rows are independent, hdfs-parquet-scanner.cc:

@@ -495,13 +495,25 @@ def test_entry_points_capture_into_a_graph(capi, O):
     tree = [L(0, O.OP_LT, 500), L(1, O.OP_GE, 10), AND(), L(0, O.OP_GE, 3500), L(1, O.OP_LT, 5), AND(), OR()]
     pages = [(ea, n, capi.alloc_scan_outputs(n, torch.device("cuda")))]
     plist = capi.make_page_list(pages)
+    # the tree keeps two bitmaps alive: its temporary lives in a caller workspace, so the captured
+    # launches are the per-operand plan (no hidden allocation, nothing library-owned baked in)
+    assert capi.program_workspace_bytes(chain, n) == 0
+    need = capi.program_workspace_bytes(tree, n)
+    assert need >= ((n + 63) // 64) * 8
+    ws_tree = torch.empty(need, dtype=torch.uint8, device="cuda")
+    with pytest.raises(capi.IpsError):      # a tree that needs a workspace does not get one
+        import ctypes as C
+        arr_n = (capi.Node * len(tree))(*tree)
+        arr_c = (capi.Column * len(cols))(*cols)
+        capi._ck(capi.lib().ips_eval_program(arr_n, len(tree), arr_c, len(cols), C.c_int64(n),
+                                             C.c_void_p(bm_tree.data_ptr()), None, capi._stream()))
 
     def work():
         capi.fle_pred(ea, n, 12, O.OP_LT, 1000, bitmap=bm_pred)
         capi.fle_scan(ea, n, 12, O.OP_LT, 1000, outputs=outs)
         capi.fle_scan_pages(plist, 12, O.OP_GE, 2000)
         capi.eval_program(chain, cols, n, bitmap=bm_chain)
-        capi.eval_program(tree, cols, n, bitmap=bm_tree)
+        capi.eval_program(tree, cols, n, bitmap=bm_tree, workspace=ws_tree)
 
     work()                                   # warm-up outside the capture (module loading etc.)
     torch.cuda.synchronize()
