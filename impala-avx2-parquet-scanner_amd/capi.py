@@ -40,6 +40,7 @@ SYMBOLS = [
     "ips_assemble_workspace_bytes", "ips_bitmap_compress",
     "ips_dict_open", "ips_dict_close", "ips_dict_num_entries", "ips_dict_bit_width", "ips_dict_encode",
     "ips_dict_encode_workspace_bytes", "ips_program_workspace_bytes",
+    "ips_nullable_workspace_bytes", "ips_fle_pred_nullable", "ips_dict_pred_nullable",
     "ips_dict_translate", "ips_dict_pred", "ips_dict_decode", "ips_dict_scan", "ips_dict_select",
     "ips_plain_stride", "ips_plain_pred", "ips_plain_scan", "ips_plain_select",
     "ips_bitmap_and", "ips_bitmap_or", "ips_bitmap_fill", "ips_bitmap_count",
@@ -57,7 +58,8 @@ class IpsError(RuntimeError):
 
 class Column(C.Structure):
     _fields_ = [("encoding", C.c_int32), ("bit_width", C.c_int32), ("type", C.c_int32),
-                ("reserved", C.c_int32), ("d_data", C.c_void_p)]
+                ("max_def_level", C.c_int32), ("d_data", C.c_void_p), ("d_def_levels", C.c_void_p),
+                ("def_bit_width", C.c_int32), ("reserved", C.c_int32), ("n_data_rows", C.c_int64)]
 
 
 class TupleColumn(C.Structure):
@@ -91,9 +93,9 @@ def lib():
         L.ips_dict_num_entries.argtypes = [C.c_void_p]
         L.ips_dict_bit_width.argtypes = [C.c_int64]
         L.ips_program_workspace_bytes.restype = C.c_size_t
-        L.ips_program_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int64]
+        L.ips_program_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64]
         for name in ("ips_batches_workspace_bytes", "ips_expand_workspace_bytes",
-                     "ips_dict_encode_workspace_bytes"):
+                     "ips_dict_encode_workspace_bytes", "ips_nullable_workspace_bytes"):
             getattr(L, name).restype = C.c_size_t
             getattr(L, name).argtypes = [C.c_int64]
         _lib = L
@@ -177,6 +179,25 @@ def fle_pred(enc, n_rows, bw, op, values, bitmap=None, stream=None):
         bitmap = torch.empty(max(_words(n_rows), 2), dtype=torch.int64, device=enc.device)
     _ck(lib().ips_fle_pred(_ptr(enc), C.c_int64(n_rows), bw, op, p, k, _ptr(bitmap),
                            _stream(stream)))
+    return bitmap[:_words(n_rows)]
+
+
+def nullable_workspace(n_rows, device):
+    return torch.empty(max(int(lib().ips_nullable_workspace_bytes(n_rows)), 16), dtype=torch.uint8,
+                       device=device)
+
+
+def fle_pred_nullable(def_levels, def_bw, max_def, n_rows, data_enc, n_data_rows, bw, op, values,
+                      bitmap=None, workspace=None, stream=None):
+    """Predicate on an OPTIONAL FLE column: def levels + data blocks -> bitmap over all rows."""
+    keep, p, k = _consts(values)
+    if bitmap is None:
+        bitmap = torch.empty(max(_words(n_rows), 2), dtype=torch.int64, device=def_levels.device)
+    if workspace is None:
+        workspace = nullable_workspace(n_rows, def_levels.device)
+    _ck(lib().ips_fle_pred_nullable(_ptr(def_levels), def_bw, max_def, C.c_int64(n_rows),
+                                    _ptr(data_enc), C.c_int64(n_data_rows), bw, op, p, k,
+                                    _ptr(bitmap), _ptr(workspace), _stream(stream)))
     return bitmap[:_words(n_rows)]
 
 
@@ -336,6 +357,22 @@ class Dict:
         return bitmap[:_words(n_rows)], bvals, counts[:n_batches(n_rows)]
 
 
+def _dict_pred_nullable(self, def_levels, def_bw, max_def, n_rows, codes_enc, n_data_rows, bw, op,
+                        literals, bitmap=None, workspace=None, stream=None):
+    keep, p, k = self._lits(literals)
+    if bitmap is None:
+        bitmap = torch.empty(max(_words(n_rows), 2), dtype=torch.int64, device=def_levels.device)
+    if workspace is None:
+        workspace = nullable_workspace(n_rows, def_levels.device)
+    _ck(lib().ips_dict_pred_nullable(self.h, _ptr(def_levels), def_bw, max_def, C.c_int64(n_rows),
+                                     _ptr(codes_enc), C.c_int64(n_data_rows), bw, op, p, k,
+                                     _ptr(bitmap), _ptr(workspace), _stream(stream)))
+    return bitmap[:_words(n_rows)]
+
+
+Dict.pred_nullable = _dict_pred_nullable
+
+
 def _dict_select(self, codes_enc, n_rows, bw, bitmap, stream=None):
     _, bvals, counts = alloc_scan_outputs(n_rows, codes_enc.device, TORCH_SLOT[self.type])
     _ck(lib().ips_dict_select(self.h, _ptr(codes_enc), C.c_int64(n_rows), bw, _ptr(bitmap),
@@ -482,15 +519,24 @@ def fle_column(enc, bw):
     return c
 
 
+def nullable_fle_column(def_levels, def_bw, max_def, enc, bw, n_data_rows):
+    """An OPTIONAL FLE column: definition levels of all rows + the data blocks of the non-NULL rows."""
+    c = Column()
+    c.encoding, c.bit_width, c.type, c.d_data = COL_FLE, bw, 0, enc.data_ptr()
+    c.max_def_level, c.d_def_levels, c.def_bit_width, c.n_data_rows = max_def, def_levels.data_ptr(), def_bw, n_data_rows
+    return c
+
+
 def plain_column(page, type_):
     c = Column()
     c.encoding, c.bit_width, c.type, c.d_data = COL_PLAIN, 0, type_, page.data_ptr()
     return c
 
 
-def program_workspace_bytes(nodes, n_rows):
+def program_workspace_bytes(nodes, cols, n_rows):
     arr_n = (Node * len(nodes))(*nodes)
-    return int(lib().ips_program_workspace_bytes(arr_n, len(nodes), n_rows))
+    arr_c = (Column * len(cols))(*cols)
+    return int(lib().ips_program_workspace_bytes(arr_n, len(nodes), arr_c, len(cols), n_rows))
 
 
 def eval_program(nodes, cols, n_rows, bitmap=None, device=None, stream=None, workspace=None):
@@ -502,7 +548,7 @@ def eval_program(nodes, cols, n_rows, bitmap=None, device=None, stream=None, wor
     if bitmap is None:
         bitmap = torch.empty(max(_words(n_rows), 2), dtype=torch.int64, device=device)
     if workspace is None:
-        need = int(lib().ips_program_workspace_bytes(arr_n, len(nodes), n_rows))
+        need = int(lib().ips_program_workspace_bytes(arr_n, len(nodes), arr_c, len(cols), n_rows))
         if need:
             workspace = torch.empty(need, dtype=torch.uint8, device=device)
     _ck(lib().ips_eval_program(arr_n, len(nodes), arr_c, len(cols), C.c_int64(n_rows),

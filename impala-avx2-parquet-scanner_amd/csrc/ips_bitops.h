@@ -136,6 +136,17 @@ IPS_HD void planes_to_values(const uint32_t (&p)[W], uint32_t (&v)[32]) {
   }
 }
 
+// Planes -> the lane-packed image only (no per-row extraction): a[r], r < R, holds 32/R values side
+// by side; the value of row j (bit position pos = 31 - j) is field pos / R of a[pos % R].  The
+// scan's index-list path parks exactly these R registers in LDS (2 or 4 x 16 bytes per lane for
+// W <= 8 / 16) and lets the selected rows be fetched as bytes / halfwords.
+template <int W>
+IPS_HD void planes_to_lanes(const uint32_t (&p)[W], uint32_t (&a)[32]) {
+#pragma unroll
+  for (int i = 0; i < 32; ++i) a[i] = i < W ? p[i] : 0u;
+  transpose_lanes<LaneWidth<W>::R>(a);
+}
+
 // Values -> planes (the encoder direction): v[j] = value of row j, p[i] = plane i bits.
 template <int W>
 IPS_HD void values_to_planes(const uint32_t (&v)[32], uint32_t (&p)[W]) {
@@ -164,6 +175,14 @@ constexpr int kBlocksPerTile = 32;
 constexpr int kRowsPerTile = kBlocksPerTile * 64;  // 2048
 constexpr int kRowTileStrideDw = 36;               // 32 values + 4 dwords pad per lane (144 B)
 constexpr int kRowTileBytes = 64 * kRowTileStrideDw * 4;  // 9216
+// Index list of the scan's sparse path: byte offsets (u16) of the selected rows' values inside the
+// wave's LDS image, in row order; sub-tiles with more selected rows take the dense path.
+constexpr int kIndexListMax = 512;
+constexpr int kIndexListBytes = kIndexListMax * 2;
+constexpr int kScanWaveBytes = kRowTileBytes + kIndexListBytes;  // 10240: 4 waves x 4 workgroups = 160 KiB
+// lane stride (bytes) of the packed image: 32/64 payload bytes + pad so that the 16-byte stores of
+// 8 consecutive lanes fall into 8 different bank quads
+constexpr int packed_lane_stride(int r) { return r == 8 ? 48 : r == 16 ? 80 : 144; }
 
 constexpr int plane_stride_words(int w) { return w | 1; }
 constexpr int plane_tile_bytes(int w) { return kBlocksPerTile * plane_stride_words(w) * 8; }

@@ -326,6 +326,63 @@ static ips_status scan_common(const void* d_enc, int64_t n_rows, int bw, const P
                          d_batch_counts, d_dict, dict_entries, d_bad, s);
 }
 
+size_t ips_nullable_workspace_bytes(int64_t n_rows) { return nullable_workspace_bytes(n_rows < 0 ? 0 : n_rows); }
+
+static ips_status check_nullable(const void* d_def_levels, int def_bit_width, int max_def_level,
+                                 int64_t n_rows, int64_t n_data_rows, const void* d_bitmap,
+                                 const void* d_workspace, const char* fn) {
+  IPS_REQUIRE(n_rows >= 0 && n_data_rows >= 0, "%s: negative row count", fn);
+  IPS_REQUIRE(def_bit_width >= 1 && def_bit_width <= 32, "%s: definition-level width %d", fn, def_bit_width);
+  IPS_REQUIRE(max_def_level >= 1 && (def_bit_width == 32 || (uint64_t)max_def_level < (1ull << def_bit_width)),
+              "%s: max_def_level %d does not fit %d bits", fn, max_def_level, def_bit_width);
+  IPS_REQUIRE(n_rows == 0 || (d_def_levels && aligned16(d_def_levels)), "%s: definition levels NULL or misaligned", fn);
+  IPS_REQUIRE(n_rows == 0 || (d_bitmap && aligned16(d_bitmap)), "%s: bitmap NULL or misaligned", fn);
+  IPS_REQUIRE(n_rows == 0 || (d_workspace && aligned16(d_workspace)),
+              "%s: pass a workspace of ips_nullable_workspace_bytes() bytes", fn);
+  return IPS_OK;
+}
+
+// data predicate over the data rows -> ws.sub, then expand into the NOT-NULL positions
+static ips_status nullable_leaf(const void* d_def_levels, int def_bit_width, int max_def_level,
+                                int64_t n_rows, const void* d_data_enc, int64_t n_data_rows,
+                                int bit_width, const PredArgs& args, ConstKind kind,
+                                uint64_t* d_bitmap, void* d_workspace, hipStream_t s) {
+  if (kind == kAllFalse) return launch_bitmap_fill(d_bitmap, n_rows, 0, s);
+  const NullableWs ws = nullable_workspace(d_workspace, n_rows);
+  int root_kind = 0;
+  const uint64_t* root = nullptr;
+  ips_status st = nullable_prepare_root(d_def_levels, def_bit_width, max_def_level, n_rows, ws,
+                                        &root_kind, &root, s);
+  if (st != IPS_OK) return st;
+  int64_t n_sub = n_data_rows < n_rows ? n_data_rows : n_rows;  // a page holds no more data rows than rows
+  if (kind == kAllTrue) {
+    n_sub = n_rows;
+    st = launch_bitmap_fill(ws.sub, n_rows, 1, s);
+  } else if (n_sub > 0) {
+    st = launch_fle_pred(bit_width, reinterpret_cast<const uint64_t*>(d_data_enc), n_sub, args,
+                         reinterpret_cast<uint32_t*>(ws.sub), s);
+  }
+  if (st != IPS_OK) return st;
+  return launch_expand(root_kind, root, ws.sub, n_rows, n_sub, ws.tile_counts, d_bitmap, 0, s);
+}
+
+ips_status ips_fle_pred_nullable(const void* d_def_levels, int def_bit_width, int max_def_level,
+                                 int64_t n_rows, const void* d_data_enc, int64_t n_data_rows,
+                                 int bit_width, ips_op op, const uint64_t* consts, int n_consts,
+                                 uint64_t* d_bitmap, void* d_workspace, ips_stream stream) {
+  ips_status st = check_nullable(d_def_levels, def_bit_width, max_def_level, n_rows, n_data_rows,
+                                 d_bitmap, d_workspace, "ips_fle_pred_nullable");
+  if (st != IPS_OK) return st;
+  if (!check_fle_common(d_data_enc, n_data_rows, bit_width, "ips_fle_pred_nullable")) return IPS_ERR_INVALID_ARG;
+  PredArgs args;
+  ConstKind kind;
+  st = build_pred_args(bit_width, op, consts, n_consts, &args, &kind, "ips_fle_pred_nullable");
+  if (st != IPS_OK) return st;
+  if (n_rows == 0) return IPS_OK;
+  return nullable_leaf(d_def_levels, def_bit_width, max_def_level, n_rows, d_data_enc, n_data_rows,
+                       bit_width, args, kind, d_bitmap, d_workspace, S(stream));
+}
+
 ips_status ips_fle_scan(const void* d_enc, int64_t n_rows, int bit_width, ips_op op,
                         const uint64_t* consts, int n_consts, uint64_t* d_bitmap,
                         uint32_t* d_batch_values, uint32_t* d_batch_counts, ips_stream stream) {
@@ -642,6 +699,34 @@ ips_status ips_dict_pred(const ips_dict* dict, const void* d_codes_enc, int64_t 
   translate(dict, op, literals, n_literals, &kind, &fle_op, codes, &n_codes);
   if (kind != IPS_XL_FLE) return launch_bitmap_fill(d_bitmap, n_rows, kind == IPS_XL_ALL_TRUE, S(stream));
   return ips_fle_pred(d_codes_enc, n_rows, bit_width, fle_op, codes, n_codes, d_bitmap, stream);
+}
+
+ips_status ips_dict_pred_nullable(const ips_dict* dict, const void* d_def_levels,
+                                  int def_bit_width, int max_def_level, int64_t n_rows,
+                                  const void* d_codes_enc, int64_t n_data_rows, int bit_width,
+                                  ips_op op, const void* literals, int n_literals,
+                                  uint64_t* d_bitmap, void* d_workspace, ips_stream stream) {
+  ips_status st = check_dict_call(dict, op, literals, n_literals, "ips_dict_pred_nullable");
+  if (st != IPS_OK) return st;
+  st = check_nullable(d_def_levels, def_bit_width, max_def_level, n_rows, n_data_rows, d_bitmap,
+                      d_workspace, "ips_dict_pred_nullable");
+  if (st != IPS_OK) return st;
+  if (!check_fle_common(d_codes_enc, n_data_rows, bit_width, "ips_dict_pred_nullable")) return IPS_ERR_INVALID_ARG;
+  if (n_rows == 0) return IPS_OK;
+  ips_xl_kind kind; ips_op fle_op; int n_codes = 0;
+  uint64_t codes[IPS_MAX_IN_LIST];
+  translate(dict, op, literals, n_literals, &kind, &fle_op, codes, &n_codes);
+  PredArgs args;
+  ConstKind ck = kEvaluate;
+  if (kind == IPS_XL_FLE) {
+    st = build_pred_args(bit_width, fle_op, codes, n_codes, &args, &ck, "ips_dict_pred_nullable");
+    if (st != IPS_OK) return st;
+  } else {
+    memset(&args, 0, sizeof(args));
+    ck = kind == IPS_XL_ALL_TRUE ? kAllTrue : kAllFalse;  // ALL_TRUE = every NON-NULL row (:338-345)
+  }
+  return nullable_leaf(d_def_levels, def_bit_width, max_def_level, n_rows, d_codes_enc, n_data_rows,
+                       bit_width, args, ck, d_bitmap, d_workspace, S(stream));
 }
 
 ips_status ips_dict_decode(const ips_dict* dict, const void* d_codes_enc, int64_t n_rows,

@@ -85,13 +85,13 @@ __device__ __forceinline__ void fle_scan_body(
     typename GatherT<G>::type* __restrict__ batch_values, uint32_t* __restrict__ batch_counts,
     const typename GatherT<G>::type* __restrict__ dict, uint32_t dict_entries,
     int32_t* __restrict__ bad_index, int64_t first_tile, int64_t stride) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kRowTileBytes / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kScanWaveBytes / 4];
   using GT = typename GatherT<G>::type;
   __shared__ GT dict_lds[DictLds<W, G>::kEntries];
   constexpr int L = (16 * W + kWave - 1) / kWave;
   const int lane = lane_id();
   const int wave = wave_id();
-  uint32_t* lds32 = lds_all + wave * (kRowTileBytes / 4);
+  uint32_t* lds32 = lds_all + wave * (kScanWaveBytes / 4);
   if constexpr (DictLds<W, G>::kUse) {
     for (uint32_t i = threadIdx.x; i < dict_entries && i < (uint32_t)DictLds<W, G>::kEntries; i += kThreads)
       dict_lds[i] = dict[i];
@@ -196,7 +196,14 @@ __device__ __forceinline__ void fle_scan_body(
       #ifndef IPS_GATHER_WIDE
 #define IPS_GATHER_WIDE 0  // dev knob: rows per lane up to which w > 16 takes this path (measured: off)
 #endif
-      constexpr uint32_t kGatherLaneMax = W <= 4 ? 12 : W <= 8 ? 8 : W <= 12 ? 5 : W <= 16 ? 4 : IPS_GATHER_WIDE;
+#ifndef IPS_GATHER_MAX_4
+#define IPS_GATHER_MAX_4 12
+#define IPS_GATHER_MAX_8 5
+#define IPS_GATHER_MAX_12 3
+#define IPS_GATHER_MAX_16 2
+#endif
+      constexpr uint32_t kGatherLaneMax = W <= 4 ? IPS_GATHER_MAX_4 : W <= 8 ? IPS_GATHER_MAX_8 : W <= 12 ? IPS_GATHER_MAX_12
+                                        : W <= 16 ? IPS_GATHER_MAX_16 : IPS_GATHER_WIDE;
       if (!kInTable && kGatherLaneMax != 0 &&
           __builtin_amdgcn_ballot_w64(mine > kGatherLaneMax) == 0ull) {
         uint32_t m = bm;
@@ -227,13 +234,80 @@ __device__ __forceinline__ void fle_scan_body(
         tile = next;
         continue;
       }
-      if (!kInTable) planes_to_values<W>(p, v);
-      wave_lds_fence();  // all plane reads precede the overwrite of the same LDS region
-      if (__builtin_amdgcn_ballot_w64(mine > kSparseLaneMax) == 0ull) {
-        // Sparse path (the common case up to ~15 % selectivity).  Each lane parks its 32 values
-        // in its own slot of the row tile (8 x 16-byte LDS stores, no cross-lane traffic) and
-        // walks the set bits of its mask, four per round, scattering straight to the batch in
-        // HBM: the stores of a round cover consecutive slots of consecutive lanes.
+#ifndef IPS_INDEX_PATH
+#define IPS_INDEX_PATH 1
+#endif
+      constexpr int R = LaneWidth<W>::R;
+      constexpr bool kPacked = IPS_INDEX_PATH && !kInTable && R < 32;  // values stay lane-packed
+      const bool index_path = IPS_INDEX_PATH ? count <= (uint32_t)kIndexListMax
+                                             : __builtin_amdgcn_ballot_w64(mine > kSparseLaneMax) == 0ull;
+      if (IPS_INDEX_PATH && index_path) {
+        // Index-list path (up to 25 % selectivity).  The lane parks its 32 values in LDS -- as
+        // bytes / halfwords for W <= 8 / 16 (the lane-packed registers as they are: 2 / 4 x 16
+        // bytes), as dwords above -- and appends the LDS byte offset of each of ITS selected rows
+        // to the sub-tile's index list at its prefix position (one ds_write_b16 per selected row:
+        // the only per-lane, imbalanced loop, a handful of instructions per round).  The list is
+        // then consumed 64 entries per round by all lanes: entry -> value -> batch slot, so the
+        // stores to HBM are full 256-byte rows of consecutive lanes whatever the bitmap looks like.
+        uint8_t* lds8 = reinterpret_cast<uint8_t*>(lds32);
+        constexpr int kStride = packed_lane_stride(kPacked ? R : 32);
+        if (kPacked) {
+          uint32_t a[32];
+          planes_to_lanes<W>(p, a);
+          wave_lds_fence();  // all plane reads precede the overwrite of the same LDS region
+#pragma unroll
+          for (int i = 0; i < R / 4; ++i) {
+            u32x4 t = {a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]};
+            *reinterpret_cast<u32x4*>(lds8 + lane * kStride + 16 * i) = t;
+          }
+        } else {
+          if (!kInTable) planes_to_values<W>(p, v);
+          wave_lds_fence();
+          values_to_row_tile(lds32, lane, v);
+        }
+        // phase A: one list entry (lane << 5 | row) per selected row.  Every lane runs the same
+        // straight-line round -- lowest set bit, store under the exec mask, clear it -- until no
+        // lane has a bit left; finished lanes keep clearing zero.
+        uint16_t* list = reinterpret_cast<uint16_t*>(lds8 + kRowTileBytes);
+        {
+          uint32_t m = bm;
+          uint16_t* slot = list + P;
+          const uint32_t lane5 = (uint32_t)lane << 5;
+          do {
+            if (m != 0u) *slot = (uint16_t)(lane5 | (uint32_t)__builtin_ctz(m));
+            ++slot;
+            m &= m - 1u;
+          } while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull);
+        }
+        wave_lds_fence();
+        // phase B: 64 entries per round, all lanes busy: entry -> LDS offset of the value -> slot
+        int bad = 0;
+        for (uint32_t i = lane; i < count; i += kWave) {
+          const uint32_t e = list[i];
+          const uint32_t src = e >> 5, j = e & 31u;
+          uint32_t x;
+          if (!kPacked) {
+            x = lds32[src * kRowTileStrideDw + j];
+          } else if (R == 16) {
+            x = *reinterpret_cast<const uint16_t*>(lds8 + src * kStride + 4u * ((31u - j) & 15u) + 2u * ((31u - j) >> 4));
+          } else {
+            x = lds8[src * kStride + 4u * ((31u - j) & 7u) + ((31u - j) >> 3)];
+          }
+          if (G == 0) {
+            dst[i] = (GT)x;
+          } else if (x < dict_entries) {
+            dst[i] = lookup(x);
+          } else {
+            bad = 1;
+          }
+        }
+        if (G != 0 && bad && bad_index) *bad_index = 1;
+      } else if (!IPS_INDEX_PATH && index_path) {
+        // Round-1 sparse path (dev comparison, IPS_INDEX_PATH=0): each lane parks its 32 values in
+        // its own slot of the row tile and walks the set bits of its mask, four per round,
+        // scattering straight to the batch in HBM.
+        if (!kInTable) planes_to_values<W>(p, v);
+        wave_lds_fence();
         values_to_row_tile(lds32, lane, v);
         const uint32_t* mine_lds = lds32 + lane * kRowTileStrideDw;
         uint32_t m = bm;
@@ -265,6 +339,8 @@ __device__ __forceinline__ void fle_scan_body(
         }
         if (G != 0 && bad && bad_index) *bad_index = 1;
       } else {
+        if (!kInTable) planes_to_values<W>(p, v);
+        wave_lds_fence();
         compact_lane_values(lds32, bm, P, v);
         wave_lds_fence();
         if (G == 0) {

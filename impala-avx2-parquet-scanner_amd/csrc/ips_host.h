@@ -62,4 +62,30 @@ ips_status launch_plain_pred(int type, const void* page, int64_t n_rows, int op,
                              int combine = 0, int join = 0, int op2 = 0,
                              const void* literal2 = nullptr);
 
+// rank-based kernels (ips_rank.hip).  root_kind 0: bitmap words, 1: width-1 definition levels
+// with max_def_level 1 (the level words are the NOT-NULL bits, MSB first)
+int64_t rank_tiles(int64_t n_rows);
+size_t rank_workspace_bytes(int64_t n_rows);
+ips_status launch_rank_tile_counts(int root_kind, const uint64_t* root, int64_t n_rows,
+                                   uint32_t* tile_counts, hipStream_t s);
+ips_status launch_expand(int root_kind, const uint64_t* root, const uint64_t* sub, int64_t n_rows,
+                         int64_t n_sub_bits, const uint32_t* tile_counts, uint64_t* out,
+                         int combine, hipStream_t s);
+ips_status launch_bitmap_fill(uint64_t* a, int64_t n_rows, int value, hipStream_t s);
+
+// Workspace of a nullable predicate leaf: tile counts | data-row bitmap | NOT-NULL bitmap (the
+// last only when the definition levels are wider than one bit).
+struct NullableWs {
+  uint32_t* tile_counts;
+  uint64_t* sub;
+  uint64_t* nonnull;
+};
+size_t nullable_workspace_bytes(int64_t n_rows);
+NullableWs nullable_workspace(void* d_workspace, int64_t n_rows);
+// NOT-NULL root of an OPTIONAL column: returns the root kind and pointer after (if the levels are
+// wider than a bit) evaluating def == max_def into ws.nonnull; then counts the tiles.
+ips_status nullable_prepare_root(const void* d_def_levels, int def_bit_width, int max_def_level,
+                                 int64_t n_rows, const NullableWs& ws, int* root_kind,
+                                 const uint64_t** root, hipStream_t s);
+
 }  // namespace ips

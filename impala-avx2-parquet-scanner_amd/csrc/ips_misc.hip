@@ -615,56 +615,7 @@ __device__ __forceinline__ uint64_t deposit_bits(uint64_t src, uint64_t mask, co
   return (uint64_t)out[0] | ((uint64_t)out[1] << 32);
 }
 
-__global__ __launch_bounds__(kScanThreads) void bitmap_expand_kernel(
-    const uint64_t* __restrict__ root, const uint64_t* __restrict__ sub, int64_t n_rows,
-    const uint64_t* __restrict__ block_offsets, uint64_t* __restrict__ out) {
-  __shared__ uint8_t dep_lut[256], ext_lut[256];
-  nibble_tables_init(dep_lut, ext_lut);
-  const int64_t n_words = (n_rows + 63) / 64;
-  const int64_t base = (int64_t)blockIdx.x * kScanItems + (int64_t)threadIdx.x * kScanPerThread;
-  PopcItems items{root, n_rows};
-  uint32_t pc[kScanPerThread];
-  uint32_t v = 0;
-#pragma unroll
-  for (int e = 0; e < kScanPerThread; ++e) {
-    pc[e] = base + e < n_words ? items(base + e) : 0u;
-    v += pc[e];
-  }
-  uint32_t total;
-  uint64_t off = block_offsets[blockIdx.x] + block_exclusive_scan(v, &total);
-#pragma unroll
-  for (int e = 0; e < kScanPerThread; ++e) {
-    if (base + e < n_words) {
-      uint64_t m = root[base + e];
-      int64_t valid = n_rows - (base + e) * 64;
-      if (valid < 64) m &= (1ull << valid) - 1ull;
-      uint64_t bits = 0;
-      if (pc[e]) {
-        const int sh = (int)(off & 63);
-        bits = sub[off >> 6] >> sh;
-        if (sh + (int)pc[e] > 64) bits |= sub[(off >> 6) + 1] << (64 - sh);
-      }
-      out[base + e] = deposit_bits(bits, m, dep_lut);
-      off += pc[e];
-    }
-  }
-}
-
-ips_status launch_bitmap_expand(const uint64_t* root, const uint64_t* sub, int64_t n_rows,
-                                uint64_t* out, void* workspace, hipStream_t s) {
-  const int64_t n_words = (n_rows + 63) / 64;
-  if (n_words <= 0) return IPS_OK;
-  const int64_t nb = (n_words + kScanItems - 1) / kScanItems;
-  uint64_t* totals = reinterpret_cast<uint64_t*>(workspace);
-  hipLaunchKernelGGL((scan_block_totals_kernel<PopcItems>), dim3((unsigned)nb), dim3(kScanThreads),
-                     0, s, PopcItems{root, n_rows}, n_words, totals);
-  hipLaunchKernelGGL(scan_of_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, totals, nb,
-                     (int64_t*)nullptr);
-  hipLaunchKernelGGL(bitmap_expand_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, s, root, sub,
-                     n_rows, totals, out);
-  IPS_HIP_TRY(hipGetLastError());
-  return IPS_OK;
-}
+// (IntersectBitset itself -- expand -- lives in ips_rank.hip.)
 
 // ---- bitmap compress (inverse of IntersectBitset) ---------------------------------------------
 __device__ __forceinline__ uint64_t extract_bits(uint64_t src, uint64_t mask, const uint8_t* ext) {

@@ -377,8 +377,21 @@ struct ChainItem {
   int join;             // 1 AND / 2 OR between a and b
 };
 
+// Temporaries of the OPTIONAL columns of one call: per column the rank table (+ NOT-NULL bitmap
+// when the levels are wider than a bit), prepared once; one data-row bitmap shared by all leaves
+// (work on a stream is ordered).
+struct NullableCol {
+  int root_kind = 0;
+  const uint64_t* root = nullptr;
+  const uint32_t* tile_counts = nullptr;
+};
+struct NullableCtx {
+  NullableCol col[IPS_PROGRAM_MAX_COLS];
+  uint64_t* sub = nullptr;
+};
+
 ips_status emit_item(const ChainItem& it, int combine, const ips_column* cols, int64_t n_rows,
-                     uint64_t* d_bitmap, hipStream_t s) {
+                     uint64_t* d_bitmap, const NullableCtx& nctx, hipStream_t s) {
   const ips_column& c = cols[it.a->column];
   if (c.encoding == IPS_COL_FLE) {
     PredArgs args;
@@ -391,6 +404,20 @@ ips_status emit_item(const ChainItem& it, int combine, const ips_column* cols, i
       args.join = it.join;
       args.op2 = it.b->op;
       args.const2 = (uint32_t)it.b->consts[0];
+    }
+    if (c.max_def_level > 0) {
+      // ColumnReader's nullable branch (hdfs-parquet-scanner.cc:338-345): the predicate over the
+      // data rows, then IntersectBitset into the NOT-NULL positions, combined into the target
+      const NullableCol& nc = nctx.col[it.a->column];
+      const int64_t n_sub = c.n_data_rows < n_rows ? c.n_data_rows : n_rows;
+      args.combine = 0;
+      if (n_sub > 0) {
+        ips_status st = launch_fle_pred(c.bit_width, reinterpret_cast<const uint64_t*>(c.d_data), n_sub,
+                                        args, reinterpret_cast<uint32_t*>(nctx.sub), s);
+        if (st != IPS_OK) return st;
+      }
+      return launch_expand(nc.root_kind, nc.root, nctx.sub, n_rows, n_sub, nc.tile_counts, d_bitmap,
+                           combine, s);
     }
     return launch_fle_pred(c.bit_width, reinterpret_cast<const uint64_t*>(c.d_data), n_rows, args,
                            reinterpret_cast<uint32_t*>(d_bitmap), s);
@@ -465,9 +492,49 @@ size_t plan_slot_bytes(int64_t n_rows) {
   return (bitmap_bytes + 255) & ~(size_t)255;
 }
 
-ips_status run_plan(const Plan& pl, const ips_column* cols, int64_t n_rows, uint64_t* d_bitmap,
-                    uint8_t* temp, hipStream_t s) {
+// workspace: [plan slots beyond the root] [shared data-row bitmap] [per OPTIONAL column: rank table,
+// NOT-NULL bitmap]
+bool column_used(const ips_node* nodes, int n_nodes, int col) {
+  for (int i = 0; i < n_nodes; ++i)
+    if (nodes[i].kind == IPS_NODE_LEAF && nodes[i].column == col) return true;
+  return false;
+}
+
+size_t nullable_part_bytes(const ips_node* nodes, int n_nodes, const ips_column* cols, int n_cols,
+                           int64_t n_rows) {
+  size_t bytes = 0;
+  for (int c = 0; c < n_cols; ++c)
+    if (cols[c].max_def_level > 0 && column_used(nodes, n_nodes, c))
+      bytes += rank_workspace_bytes(n_rows) + plan_slot_bytes(n_rows);
+  return bytes ? bytes + plan_slot_bytes(n_rows) : 0;
+}
+
+ips_status run_plan(const Plan& pl, const ips_node* nodes, int n_nodes, const ips_column* cols,
+                    int n_cols, int64_t n_rows, uint64_t* d_bitmap, uint8_t* temp, hipStream_t s) {
   const size_t slot_bytes = plan_slot_bytes(n_rows);
+  NullableCtx nctx;
+  {
+    uint8_t* p = temp + slot_bytes * (size_t)(pl.n_slots > 1 ? pl.n_slots - 1 : 0);
+    bool any = false;
+    for (int c = 0; c < n_cols; ++c) any = any || (cols[c].max_def_level > 0 && column_used(nodes, n_nodes, c));
+    if (any) {
+      nctx.sub = reinterpret_cast<uint64_t*>(p);
+      p += slot_bytes;
+      for (int c = 0; c < n_cols; ++c) {
+        if (cols[c].max_def_level <= 0 || !column_used(nodes, n_nodes, c)) continue;
+        NullableWs ws;
+        ws.tile_counts = reinterpret_cast<uint32_t*>(p);
+        ws.sub = nctx.sub;
+        ws.nonnull = reinterpret_cast<uint64_t*>(p + rank_workspace_bytes(n_rows));
+        p += rank_workspace_bytes(n_rows) + slot_bytes;
+        ips_status st = nullable_prepare_root(cols[c].d_def_levels, cols[c].def_bit_width,
+                                              cols[c].max_def_level, n_rows, ws, &nctx.col[c].root_kind,
+                                              &nctx.col[c].root, s);
+        if (st != IPS_OK) return st;
+        nctx.col[c].tile_counts = ws.tile_counts;
+      }
+    }
+  }
   auto slot_ptr = [&](int slot) -> uint64_t* {
     if (slot == pl.root) return d_bitmap;
     return reinterpret_cast<uint64_t*>(temp + slot_bytes * (size_t)(slot < pl.root ? slot : slot - 1));
@@ -475,7 +542,7 @@ ips_status run_plan(const Plan& pl, const ips_column* cols, int64_t n_rows, uint
   ips_status st = IPS_OK;
   for (int i = 0; i < pl.n_steps && st == IPS_OK; ++i) {
     const Step& p = pl.steps[i];
-    if (p.kind == 0) st = emit_item(ChainItem{false, p.item.a, p.item.b, p.item.join}, p.combine, cols, n_rows, slot_ptr(p.dst), s);
+    if (p.kind == 0) st = emit_item(ChainItem{false, p.item.a, p.item.b, p.item.join}, p.combine, cols, n_rows, slot_ptr(p.dst), nctx, s);
     else st = launch_bitmap_binop(p.combine == 1 ? 0 : 1, slot_ptr(p.dst), slot_ptr(p.src), (n_rows + 63) / 64, s);
   }
   return st;
@@ -483,11 +550,17 @@ ips_status run_plan(const Plan& pl, const ips_column* cols, int64_t n_rows, uint
 
 }  // namespace
 
-extern "C" size_t ips_program_workspace_bytes(const ips_node* nodes, int n_nodes, int64_t n_rows) {
+extern "C" size_t ips_program_workspace_bytes(const ips_node* nodes, int n_nodes,
+                                              const ips_column* cols, int n_cols, int64_t n_rows) {
   if (!nodes || n_nodes < 1 || n_nodes > IPS_PROGRAM_MAX_NODES || n_rows <= 0) return 0;
+  for (int i = 0; i < n_nodes; ++i)
+    if (nodes[i].kind == IPS_NODE_LEAF && (nodes[i].column < 0 || nodes[i].column >= n_cols)) return 0;
   Plan pl;
-  if (!make_plan(nodes, n_nodes, &pl) || pl.n_slots <= 1) return 0;
-  return plan_slot_bytes(n_rows) * (size_t)(pl.n_slots - 1);
+  if (!make_plan(nodes, n_nodes, &pl)) return 0;
+  size_t bytes = pl.n_slots > 1 ? plan_slot_bytes(n_rows) * (size_t)(pl.n_slots - 1) : 0;
+  if (cols && n_cols >= 1 && n_cols <= IPS_PROGRAM_MAX_COLS)
+    bytes += nullable_part_bytes(nodes, n_nodes, cols, n_cols, n_rows);
+  return bytes;
 }
 
 extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const ips_column* cols,
@@ -503,6 +576,7 @@ extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const
   memset(&prog, 0, sizeof(prog));
   prog.n_nodes = n_nodes;
   int depth = 0, max_depth = 0, n_leaves = 0;
+  bool any_nullable = false;
   const void* last_staged = nullptr;
   for (int i = 0; i < n_nodes; ++i) {
     const ips_node& nd = nodes[i];
@@ -517,6 +591,17 @@ extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const
       const ips_column& c = cols[nd.column];
       IPS_REQUIRE(n_rows == 0 || (c.d_data && aligned16(c.d_data)),
                   "ips_eval_program: column %d: data NULL or misaligned", nd.column);
+      IPS_REQUIRE(c.max_def_level >= 0, "ips_eval_program: column %d: max_def_level < 0", nd.column);
+      if (c.max_def_level > 0) {
+        IPS_REQUIRE(c.encoding == IPS_COL_FLE, "ips_eval_program: column %d: OPTIONAL columns must be FLE", nd.column);
+        IPS_REQUIRE(c.def_bit_width >= 1 && c.def_bit_width <= 32 &&
+                    (c.def_bit_width == 32 || (uint64_t)c.max_def_level < (1ull << c.def_bit_width)),
+                    "ips_eval_program: column %d: max_def_level does not fit the level width", nd.column);
+        IPS_REQUIRE(n_rows == 0 || (c.d_def_levels && aligned16(c.d_def_levels)),
+                    "ips_eval_program: column %d: definition levels NULL or misaligned", nd.column);
+        IPS_REQUIRE(c.n_data_rows >= 0, "ips_eval_program: column %d: n_data_rows < 0", nd.column);
+        any_nullable = true;
+      }
       if (c.encoding == IPS_COL_FLE) {
         IPS_REQUIRE(c.bit_width >= 1 && c.bit_width <= 32, "ips_eval_program: column %d: bit width", nd.column);
         const uint64_t limit = c.bit_width == 32 ? 0xFFFFFFFFull : ((1ull << c.bit_width) - 1ull);
@@ -574,12 +659,16 @@ extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const
   if (getenv("IPS_PROGRAM_NO_CHAIN") == nullptr) {  // dev knob: force the one-launch kernel
     Plan pl;
     if (make_plan(nodes, n_nodes, &pl)) {
-      IPS_REQUIRE(pl.n_slots <= 1 || (d_workspace && aligned16(d_workspace)),
-                  "ips_eval_program: this tree keeps %d bitmaps alive: pass a workspace of "
-                  "ips_program_workspace_bytes() bytes", pl.n_slots);
-      return run_plan(pl, cols, n_rows, d_bitmap, reinterpret_cast<uint8_t*>(d_workspace),
-                      reinterpret_cast<hipStream_t>(stream));
+      IPS_REQUIRE((pl.n_slots <= 1 && !any_nullable) || (d_workspace && aligned16(d_workspace)),
+                  "ips_eval_program: this tree needs temporaries (%d bitmaps alive%s): pass a workspace of "
+                  "ips_program_workspace_bytes() bytes", pl.n_slots, any_nullable ? ", OPTIONAL columns" : "");
+      return run_plan(pl, nodes, n_nodes, cols, n_cols, n_rows, d_bitmap,
+                      reinterpret_cast<uint8_t*>(d_workspace), reinterpret_cast<hipStream_t>(stream));
     }
+  }
+  if (any_nullable) {
+    set_error("ips_eval_program: OPTIONAL columns are evaluated by the per-operand plan only");
+    return IPS_ERR_UNSUPPORTED;
   }
   return launch_program(prog, n_rows, reinterpret_cast<uint32_t*>(d_bitmap),
                         reinterpret_cast<hipStream_t>(stream));

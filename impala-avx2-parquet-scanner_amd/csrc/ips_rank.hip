@@ -1,0 +1,291 @@
+// ips_rank.hip -- rank-based bitmap kernels: ColumnReader::IntersectBitset (expand) for OPTIONAL
+// columns and the fused nullable predicate leaf built on it.
+//
+// The reference evaluates a predicate on a nullable dictionary page in three steps
+// (hdfs-parquet-scanner.cc:338-345): fle_def_levels_->Eq(n, bits, max_def_level) -> NOT-NULL
+// bitmap, the data predicate over bits.count() values, and IntersectBitset (:326-331), which walks
+// the root bits one at a time and replaces every 1 by the next data bit.  Here:
+//   1. the data predicate runs over the whole data buffer with the stand-alone predicate kernels
+//      (its row count is never needed on the host: the buffer's size bounds it),
+//   2. rank_tile_counts_kernel counts the non-NULL rows of every 262144-row tile straight from the
+//      definition levels (width 1, max_def 1: the level words ARE the NOT-NULL bits, MSB first),
+//   3. expand_kernel gives every output word its rank (tile base = sum of the tile counts before
+//      it, re-summed per workgroup from L2; inside the tile a wave-level DPP scan), fetches the
+//      64-bit window of data bits at that rank and deposits it into the NOT-NULL positions
+//      (four mask bits at a time through a 256-entry table in LDS), optionally AND-ing / OR-ing
+//      into an existing bitmap (ips_eval_program's combine modes).
+// HBM traffic: def levels twice (n/8 bytes each), the data bitmap once in, the result once out.
+#include "ips_host.h"
+
+namespace ips {
+
+constexpr int kRankThreads = 256;
+constexpr int kRankRounds = 8;                                   // 16-byte loads per lane
+constexpr int kRankWordsPerWave = kWave * 2 * kRankRounds;        // 1024 words = 65536 rows
+constexpr int kRankWordsPerTile = kRankWordsPerWave * (kRankThreads / kWave);  // 4096 words
+
+typedef unsigned long long u64;
+
+// Root word i as a NOT-NULL mask in bitmap order, rows >= n_rows cleared.
+//   kRootBitmap: an ordinary bitmap word (LSB = first row)
+//   kRootLevels1: a width-1 FLE block of definition levels with max_def_level 1 (row k at bit
+//                 63-k, fle-encoding.h:8338-8340): the mask is the bit-reversed word
+enum RootKind { kRootBitmap = 0, kRootLevels1 = 1 };
+
+template <int ROOT>
+__device__ __forceinline__ u64 root_mask(u64 w, int64_t word, int64_t n_rows) {
+  if (ROOT == kRootLevels1) w = __builtin_bitreverse64(w);
+  const int64_t valid = n_rows - word * 64;
+  if (valid < 64) w = valid <= 0 ? 0ull : (w & ((1ull << valid) - 1ull));
+  return w;
+}
+
+// the wave's 8 x 2 root words of tile 'tile' (word index of (round r, lane, e) =
+// first + r * 128 + 2 * lane + e), masked; words beyond n_words are zero
+template <int ROOT>
+__device__ __forceinline__ void load_root(const u64* __restrict__ root, int64_t first,
+                                          int64_t n_words, int64_t n_rows, int lane,
+                                          u64 (&m)[kRankRounds][2]) {
+#pragma unroll
+  for (int r = 0; r < kRankRounds; ++r) {
+    const int64_t w0 = first + r * 128 + 2 * lane;
+    u64 a = 0, b = 0;
+    if (w0 + 1 < n_words) {
+      u32x4 t = stream_load<true>(reinterpret_cast<const u32x4*>(root + w0));
+      a = ((u64)t.y << 32) | t.x;
+      b = ((u64)t.w << 32) | t.z;
+    } else if (w0 < n_words) {
+      a = root[w0];
+    }
+    m[r][0] = root_mask<ROOT>(a, w0, n_rows);
+    m[r][1] = root_mask<ROOT>(b, w0 + 1, n_rows);
+  }
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
+  return __builtin_amdgcn_readlane(wave_inclusive_scan(x), 63);
+}
+
+template <int ROOT>
+__global__ __launch_bounds__(kRankThreads) void rank_tile_counts_kernel(
+    const u64* __restrict__ root, int64_t n_rows, uint32_t* __restrict__ tile_counts) {
+  __shared__ uint32_t wave_tot[kRankThreads / kWave];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int64_t n_words = (n_rows + 63) / 64;
+  const int64_t first = (int64_t)blockIdx.x * kRankWordsPerTile + wave * kRankWordsPerWave;
+  u64 m[kRankRounds][2];
+  load_root<ROOT>(root, first, n_words, n_rows, lane, m);
+  uint32_t c = 0;
+#pragma unroll
+  for (int r = 0; r < kRankRounds; ++r) c += __builtin_popcountll(m[r][0]) + __builtin_popcountll(m[r][1]);
+  const uint32_t tot = wave_sum(c);
+  if (lane == 0) wave_tot[wave] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+
+// pdep of the low popcount(mask) bits of src into the set positions of mask, four mask bits at a
+// time: table[mask4 << 4 | src4].  Per nibble: two bit-field extracts (the second at the running
+// rank of the nibble inside its 32-bit half), one table read, one shift-or, one popcount-add.
+__device__ __forceinline__ u64 deposit64(u64 src, u64 mask, const uint8_t* __restrict__ lut) {
+  uint32_t out[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t mh = (uint32_t)(mask >> (32 * h));
+    const uint32_t sh = h == 0 ? (uint32_t)src : (uint32_t)(src >> __builtin_popcount((uint32_t)mask));
+    uint32_t o = 0, rank = 0;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const uint32_t m4 = (mh >> (4 * n)) & 15u;
+      const uint32_t s4 = (sh >> rank) & 15u;  // rank <= 28
+      o |= (uint32_t)lut[(m4 << 4) | s4] << (4 * n);
+      rank += (uint32_t)__builtin_popcount(m4);
+    }
+    out[h] = o;
+  }
+  return (u64)out[0] | ((u64)out[1] << 32);
+}
+
+__device__ __forceinline__ void deposit_lut_init(uint8_t* lut) {  // 256 threads: one entry each
+  const uint32_t m = threadIdx.x >> 4, v = threadIdx.x & 15u;
+  uint32_t d = 0, j = 0;
+#pragma unroll
+  for (uint32_t bit = 0; bit < 4; ++bit) {
+    if (m & (1u << bit)) {
+      if (v & (1u << j)) d |= 1u << bit;
+      ++j;
+    }
+  }
+  lut[threadIdx.x] = (uint8_t)d;
+}
+
+// out word i = deposit(sub bits [rank(i), rank(i) + popcount(root_i)), root_i), where rank(i) is the
+// number of set root bits before word i.  Data bits at or beyond n_sub_bits read as 0 (a page
+// whose NOT-NULL count exceeds its data rows selects nothing there).  combine: 0 store, 1 and,
+// 2 or into out.
+template <int ROOT>
+__global__ __launch_bounds__(kRankThreads) void expand_kernel(
+    const u64* __restrict__ root, const u64* __restrict__ sub, int64_t n_rows, int64_t n_sub_bits,
+    const uint32_t* __restrict__ tile_counts, u64* __restrict__ out, int combine) {
+  __shared__ uint8_t lut[256];
+  __shared__ u64 part[kRankThreads / kWave];
+  __shared__ uint32_t wave_tot[kRankThreads / kWave];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int64_t n_words = (n_rows + 63) / 64;
+  const int64_t n_sub_words = (n_sub_bits + 63) / 64;
+  deposit_lut_init(lut);
+  // tile base: the non-NULL rows of all tiles before this one
+  u64 before = 0;
+  for (int64_t i = threadIdx.x; i < (int64_t)blockIdx.x; i += kRankThreads) before += tile_counts[i];
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
+  if (lane == 0) part[wave] = before;
+
+  const int64_t first = (int64_t)blockIdx.x * kRankWordsPerTile + wave * kRankWordsPerWave;
+  u64 m[kRankRounds][2];
+  load_root<ROOT>(root, first, n_words, n_rows, lane, m);
+  // exclusive rank of every pair of words inside the wave: per round a DPP scan over the lanes
+  uint32_t excl[kRankRounds];
+  uint32_t run = 0;
+#pragma unroll
+  for (int r = 0; r < kRankRounds; ++r) {
+    const uint32_t c = (uint32_t)(__builtin_popcountll(m[r][0]) + __builtin_popcountll(m[r][1]));
+    const uint32_t incl = wave_inclusive_scan(c);
+    excl[r] = run + incl - c;
+    run += __builtin_amdgcn_readlane(incl, 63);
+  }
+  if (lane == 0) wave_tot[wave] = run;
+  __syncthreads();
+  u64 base = part[0] + part[1] + part[2] + part[3];
+  for (int w = 0; w < wave; ++w) base += wave_tot[w];
+
+#pragma unroll
+  for (int r = 0; r < kRankRounds; ++r) {
+    const int64_t w0 = first + r * 128 + 2 * lane;
+    if (w0 >= n_words) continue;
+    u64 res[2];
+    u64 off = base + excl[r];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const u64 mk = m[r][e];
+      const uint32_t pc = (uint32_t)__builtin_popcountll(mk);
+      u64 bits = 0;
+      if (pc) {
+        const int64_t wi = (int64_t)(off >> 6);
+        const int sh = (int)(off & 63);
+        if (wi < n_sub_words) {
+          bits = sub[wi] >> sh;
+          if (sh + (int)pc > 64 && wi + 1 < n_sub_words) bits |= sub[wi + 1] << (64 - sh);
+          const int64_t avail = n_sub_bits - (int64_t)off;
+          if (avail < 64) bits = avail <= 0 ? 0ull : (bits & ((1ull << avail) - 1ull));
+        }
+      }
+      res[e] = deposit64(bits, mk, lut);
+      off += pc;
+    }
+    if (w0 + 1 < n_words) {
+      u32x4* dst = reinterpret_cast<u32x4*>(out + w0);
+      if (combine) {
+        const u32x4 old = *dst;
+        const u64 o0 = ((u64)old.y << 32) | old.x, o1 = ((u64)old.w << 32) | old.z;
+        res[0] = combine == 1 ? (res[0] & o0) : (res[0] | o0);
+        res[1] = combine == 1 ? (res[1] & o1) : (res[1] | o1);
+      }
+      const u32x4 t = {(uint32_t)res[0], (uint32_t)(res[0] >> 32), (uint32_t)res[1], (uint32_t)(res[1] >> 32)};
+      IPS_STREAM_STORE16(dst, t);
+    } else {
+      if (combine) res[0] = combine == 1 ? (res[0] & out[w0]) : (res[0] | out[w0]);
+      out[w0] = res[0];
+    }
+  }
+}
+
+int64_t rank_tiles(int64_t n_rows) {
+  const int64_t n_words = (n_rows + 63) / 64;
+  return (n_words + kRankWordsPerTile - 1) / kRankWordsPerTile;
+}
+
+// workspace: tile counts only
+size_t rank_workspace_bytes(int64_t n_rows) { return ((size_t)rank_tiles(n_rows) * 4 + 255) & ~(size_t)255; }
+
+// root_kind: kRootBitmap / kRootLevels1.  tile_counts: rank_tiles(n_rows) uint32 (workspace).
+ips_status launch_rank_tile_counts(int root_kind, const uint64_t* root, int64_t n_rows,
+                                   uint32_t* tile_counts, hipStream_t s) {
+  const int64_t tiles = rank_tiles(n_rows);
+  if (tiles <= 0) return IPS_OK;
+  const u64* r = reinterpret_cast<const u64*>(root);
+  if (root_kind == kRootLevels1)
+    hipLaunchKernelGGL(rank_tile_counts_kernel<kRootLevels1>, dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, n_rows, tile_counts);
+  else
+    hipLaunchKernelGGL(rank_tile_counts_kernel<kRootBitmap>, dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, n_rows, tile_counts);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+ips_status launch_expand(int root_kind, const uint64_t* root, const uint64_t* sub, int64_t n_rows,
+                         int64_t n_sub_bits, const uint32_t* tile_counts, uint64_t* out,
+                         int combine, hipStream_t s) {
+  const int64_t tiles = rank_tiles(n_rows);
+  if (tiles <= 0) return IPS_OK;
+  const u64* r = reinterpret_cast<const u64*>(root);
+  const u64* sb = reinterpret_cast<const u64*>(sub);
+  u64* o = reinterpret_cast<u64*>(out);
+  if (root_kind == kRootLevels1)
+    hipLaunchKernelGGL(expand_kernel<kRootLevels1>, dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, sb, n_rows, n_sub_bits, tile_counts, o, combine);
+  else
+    hipLaunchKernelGGL(expand_kernel<kRootBitmap>, dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, sb, n_rows, n_sub_bits, tile_counts, o, combine);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+// IntersectBitset for callers that hold two bitmaps (ips_bitmap_expand): two launches.
+ips_status launch_bitmap_expand(const uint64_t* root, const uint64_t* sub, int64_t n_rows,
+                                uint64_t* out, void* workspace, hipStream_t s) {
+  if (n_rows <= 0) return IPS_OK;
+  uint32_t* counts = reinterpret_cast<uint32_t*>(workspace);
+  ips_status st = launch_rank_tile_counts(kRootBitmap, root, n_rows, counts, s);
+  if (st != IPS_OK) return st;
+  return launch_expand(kRootBitmap, root, sub, n_rows, n_rows, counts, out, 0, s);
+}
+
+// ---- nullable predicate leaf: workspace + NOT-NULL root -------------------------------------
+static size_t bitmap_slot_bytes(int64_t n_rows) {
+  return ((size_t)((n_rows + 63) / 64) * 8 + 255) & ~(size_t)255;
+}
+size_t nullable_workspace_bytes(int64_t n_rows) {
+  return rank_workspace_bytes(n_rows) + 2 * bitmap_slot_bytes(n_rows);
+}
+NullableWs nullable_workspace(void* d_workspace, int64_t n_rows) {
+  uint8_t* p = reinterpret_cast<uint8_t*>(d_workspace);
+  NullableWs ws;
+  ws.tile_counts = reinterpret_cast<uint32_t*>(p);
+  ws.sub = reinterpret_cast<uint64_t*>(p + rank_workspace_bytes(n_rows));
+  ws.nonnull = reinterpret_cast<uint64_t*>(p + rank_workspace_bytes(n_rows) + bitmap_slot_bytes(n_rows));
+  return ws;
+}
+
+ips_status nullable_prepare_root(const void* d_def_levels, int def_bit_width, int max_def_level,
+                                 int64_t n_rows, const NullableWs& ws, int* root_kind,
+                                 const uint64_t** root, hipStream_t s) {
+  if (def_bit_width == 1 && max_def_level == 1) {
+    // the usual flat OPTIONAL column: the level words are the NOT-NULL bits
+    *root_kind = kRootLevels1;
+    *root = reinterpret_cast<const uint64_t*>(d_def_levels);
+  } else {
+    // fle_def_levels_->Eq(n, bits, max_def_level), hdfs-parquet-scanner.cc:342
+    PredArgs args;
+    __builtin_memset(&args, 0, sizeof(args));
+    args.op = IPS_OP_EQ;
+    args.n_consts = 1;
+    args.consts[0] = (uint32_t)max_def_level;
+    ips_status st = launch_fle_pred(def_bit_width, reinterpret_cast<const uint64_t*>(d_def_levels),
+                                    n_rows, args, reinterpret_cast<uint32_t*>(ws.nonnull), s);
+    if (st != IPS_OK) return st;
+    *root_kind = kRootBitmap;
+    *root = ws.nonnull;
+  }
+  return launch_rank_tile_counts(*root_kind, *root, n_rows, ws.tile_counts, s);
+}
+
+}  // namespace ips

@@ -43,6 +43,34 @@ class HdfsParquetScanner {
       pending_pages_.erase(pending_pages_.begin());
       return InitDataPage(pg.data, pg.len, pg.num_values);
     }
+    // Data-page payload framing (InitDataPage, .cc:882-916): OPTIONAL columns start with
+    // [int32 n_def_bytes][FLE definition levels], then [uint8 code_width][FLE codes].  The
+    // reference bounds-checks the 4-byte read (ReadWriteUtil::Read); a short or corrupt page must
+    // not make the decoders read outside the buffer.
+    static bool SplitDataPage(uint8_t* data, int len, int max_def_level, uint8_t** def_levels,
+                              int* n_def_bytes, uint8_t** codes, int* codes_len) {
+      uint8_t* p = data;
+      int left = len;
+      *def_levels = nullptr;
+      *n_def_bytes = 0;
+      if (data == nullptr || len < 0) return false;
+      if (max_def_level > 0) {
+        if (left < 4) return false;
+        int32_t nb;
+        memcpy(&nb, p, 4);
+        p += 4; left -= 4;
+        if (nb < 0 || nb > left) return false;
+        *def_levels = p;
+        *n_def_bytes = nb;
+        p += nb; left -= nb;
+      }
+      if (left < 1) return false;  // the code-width byte (DictDecoderBase::SetData)
+      if (*p < 1 || *p > 32) return false;
+      *codes = p;
+      *codes_len = left;
+      return true;
+    }
+
    protected:
     virtual bool InitDataPage(uint8_t* data, int len, int64_t num_values) = 0;
     int64_t num_buffered_values_ = 0;
@@ -115,7 +143,8 @@ class HdfsParquetScanner {
       memset(col, 0, sizeof(*col));
       memset(node, 0, sizeof(*node));
       node->kind = IPS_NODE_LEAF;
-      if (max_def_level_ > 0 || n_lits > 16) return false;  // nullable columns: node-by-node path
+      if (n_lits > 16) return false;
+      if (max_def_level_ > 0 && !dict_decoder_) return false;  // the PLAIN branch has no NULL handling (.cc:346-348)
       if (dict_decoder_) {
         ips_xl_kind kind; ips_op fle_op; int n_codes = 0;
         uint64_t codes[16];
@@ -125,6 +154,13 @@ class HdfsParquetScanner {
         col->encoding = IPS_COL_FLE;
         col->bit_width = dict_decoder_->code_bit_width();
         col->d_data = dict_decoder_->codes()->device_blocks();
+        if (max_def_level_ > 0) {  // OPTIONAL: levels + data rows, evaluated by the nullable leaf
+          if (!fle_def_levels_ || !fle_def_levels_->usable()) return false;
+          col->max_def_level = max_def_level_;
+          col->d_def_levels = fle_def_levels_->device_blocks();
+          col->def_bit_width = fle_def_levels_->bit_width();
+          col->n_data_rows = dict_decoder_->codes()->rows_in_buffer();
+        }
         // constant answers become range predicates that are always false / true on codes
         if (kind == IPS_XL_ALL_FALSE) { node->op = IPS_OP_LT; node->n_consts = 1; node->consts[0] = 0; return true; }
         if (kind == IPS_XL_ALL_TRUE) { node->op = IPS_OP_GE; node->n_consts = 1; node->consts[0] = 0; return true; }
@@ -135,8 +171,7 @@ class HdfsParquetScanner {
       }
       col->encoding = IPS_COL_PLAIN;
       col->type = IpsTypeOf<T>::value;
-      if (!plain_dev_.get() && !plain_dev_.upload(plain_begin_, (size_t)plain_rows_ * ips_plain_stride(IpsTypeOf<T>::value)))
-        return false;
+      if (!EnsurePlainResident()) return false;
       col->d_data = plain_dev_.get();
       if (IPS_PLAIN_SEMANTICS == IPS_SEM_REFERENCE) {  // literal OP x == x OP' literal (quirk Q1)
         if (op == IPS_OP_LT) op = IPS_OP_GT; else if (op == IPS_OP_GT) op = IPS_OP_LT;
@@ -155,16 +190,16 @@ class HdfsParquetScanner {
     virtual bool InitDataPage(uint8_t* data, int len, int64_t num_values) {
       num_buffered_values_ = num_values;
       if (dict_decoder_) {
-        uint8_t* p = data;
-        int left = len;
-        if (max_def_level_ > 0) {  // .cc:882-901
-          int32_t n_def_bytes;
-          memcpy(&n_def_bytes, p, 4);
-          p += 4; left -= 4;
-          fle_def_levels_.reset(new FleDecoder(p, n_def_bytes, BitUtil::Log2((uint64_t)max_def_level_ + 1)));
-          p += n_def_bytes; left -= n_def_bytes;
+        uint8_t *def = nullptr, *codes = nullptr;
+        int n_def_bytes = 0, codes_len = 0;
+        if (!SplitDataPage(data, len, max_def_level_, &def, &n_def_bytes, &codes, &codes_len)) {
+          ips::ok(IPS_ERR_INVALID_ARG, "InitDataPage: truncated or corrupt data page");
+          num_buffered_values_ = 0;
+          return false;
         }
-        dict_decoder_->SetData(p, left);
+        if (max_def_level_ > 0)  // .cc:882-901
+          fle_def_levels_.reset(new FleDecoder(def, n_def_bytes, BitUtil::Log2((uint64_t)max_def_level_ + 1)));
+        dict_decoder_->SetData(codes, codes_len);
         return true;
       }
       data_ = plain_begin_ = data;
@@ -172,6 +207,7 @@ class HdfsParquetScanner {
       T dummy;
       data_end_ = data + num_values * ParquetPlainEncoder::ByteSize(dummy);
       plain_dev_.release();
+      plain_preds_.clear();
       return true;
     }
 
@@ -200,7 +236,12 @@ class HdfsParquetScanner {
     uint8_t* data_end_ = nullptr;
     uint8_t* plain_begin_ = nullptr;
     int64_t plain_rows_ = 0;
-    ips::DeviceBuffer plain_dev_;
+    ips::DeviceBuffer plain_dev_;     // the PLAIN page, uploaded once per InitDataPage
+    ips::PredCache plain_preds_;      // whole-page bitmaps per (op, literals)
+    bool EnsurePlainResident() {
+      return plain_dev_.get() ||
+             plain_dev_.upload(plain_begin_, (size_t)plain_rows_ * ips_plain_stride(IpsTypeOf<T>::value));
+    }
   };
 
   HdfsParquetScanner() {}
@@ -211,20 +252,20 @@ class HdfsParquetScanner {
   template <typename T>
   int AddDictionaryColumn(uint8_t* dict_page, int dict_len, uint8_t* data_page, int data_len,
                           int64_t num_values, int max_def_level = 0) {
+    uint8_t *def = nullptr, *codes = nullptr;
+    int n_def_bytes = 0, codes_len = 0;
+    if (!BaseColumnReader::SplitDataPage(data_page, data_len, max_def_level, &def, &n_def_bytes, &codes,
+                                         &codes_len)) {
+      ips::ok(IPS_ERR_INVALID_ARG, "AddDictionaryColumn: truncated or corrupt data page");
+      return -1;
+    }
     auto* r = new ColumnReader<T>();
     r->num_buffered_values_ = num_values;
     r->max_def_level_ = max_def_level;
-    uint8_t* p = data_page;
-    int left = data_len;
-    if (max_def_level > 0) {  // .cc:882-901
-      int32_t n_def_bytes;
-      memcpy(&n_def_bytes, p, 4);
-      p += 4; left -= 4;
-      r->fle_def_levels_.reset(new FleDecoder(p, n_def_bytes, BitUtil::Log2((uint64_t)max_def_level + 1)));
-      p += n_def_bytes; left -= n_def_bytes;
-    }
+    if (max_def_level > 0)  // .cc:882-901
+      r->fle_def_levels_.reset(new FleDecoder(def, n_def_bytes, BitUtil::Log2((uint64_t)max_def_level + 1)));
     r->dict_decoder_.reset(new DictDecoder<T>(dict_page, dict_len, -1));
-    r->dict_decoder_->SetData(p, left);
+    r->dict_decoder_->SetData(codes, codes_len);
     column_readers_.emplace_back(r);
     return (int)column_readers_.size() - 1;
   }
@@ -296,7 +337,8 @@ class HdfsParquetScanner {
   bool SkipValue(int idx, int skip_rows) { return column_readers_[(size_t)idx]->SkipValue(skip_rows); }
 
   // facade extra: the whole conjunct list over all rows of the pages in one ips_eval_program
-  // launch (REQUIRED columns only).  bitmap_words: ceil(num_rows/64) LSB-first words.
+  // call (REQUIRED and OPTIONAL dictionary columns, PLAIN columns).  bitmap_words:
+  // ceil(num_rows/64) LSB-first words.
   bool EvalSimplePredicatesFused(int64_t num_rows, std::vector<uint64_t>* bitmap_words) {
     lower_cols_.clear();
     std::vector<ips_node> program;
@@ -308,7 +350,8 @@ class HdfsParquetScanner {
     ips::DeviceBuffer bm(bitmap_words->size() * 8);
     // temporaries of trees that keep several bitmaps alive come from the caller (no hidden
     // allocation inside the library); kept across calls
-    const size_t ws_bytes = ips_program_workspace_bytes(program.data(), (int)program.size(), num_rows);
+    const size_t ws_bytes = ips_program_workspace_bytes(program.data(), (int)program.size(), lower_cols_.data(),
+                                                        (int)lower_cols_.size(), num_rows);
     if (ws_bytes > 0 && !program_workspace_.resize(ws_bytes)) return false;
     return ips::ok(ips_eval_program(program.data(), (int)program.size(), lower_cols_.data(),
                                     (int)lower_cols_.size(), num_rows, bm.as<uint64_t>(),
@@ -361,20 +404,41 @@ void HdfsParquetScanner::ColumnReader<T>::Call(int op, D& d, int64_t n, SkipBits
   }
 }
 
+// PLAIN pages (ParquetPlainEncoder::Eq..In(data_, ..), parquet-common.h:197-255): the reference
+// walks num_rows slots from data_ on every call.  Here the page is uploaded once per InitDataPage,
+// each distinct (op, literals) is evaluated over the WHOLE page in one ips_plain_pred launch, and
+// the 1024-row batches are served from that bitmap at the rows data_ stands at.
 template <typename T>
 template <typename L>
 void HdfsParquetScanner::ColumnReader<T>::PlainCall(int op, int64_t n, SkipBitset& b, L& lit) {
+  const T* lits;
+  int n_lits;
   if constexpr (std::is_same<L, std::vector<T>>::value) {
-    ParquetPlainEncoder::In<T>(data_, -1, n, b, lit);
+    if (IPS_PLAIN_SEMANTICS == IPS_SEM_REFERENCE || lit.empty()) return;  // reference: empty body (:252-255)
+    lits = lit.data();
+    n_lits = (int)lit.size();
   } else {
-    switch (op) {
-      case IPS_OP_EQ: ParquetPlainEncoder::Eq<T>(data_, -1, n, b, lit); break;
-      case IPS_OP_LT: ParquetPlainEncoder::Lt<T>(data_, -1, n, b, lit); break;
-      case IPS_OP_LE: ParquetPlainEncoder::Le<T>(data_, -1, n, b, lit); break;
-      case IPS_OP_GT: ParquetPlainEncoder::Gt<T>(data_, -1, n, b, lit); break;
-      default: ParquetPlainEncoder::Ge<T>(data_, -1, n, b, lit); break;
-    }
+    lits = &lit;
+    n_lits = 1;
   }
+  if (n <= 0) return;
+  const ips_type t = IpsTypeOf<T>::value;
+  const std::vector<uint64_t>* words = plain_preds_.find(op, lits, (size_t)n_lits * sizeof(T));
+  if (!words) {
+    std::vector<uint64_t>* w = plain_preds_.insert(op, lits, (size_t)n_lits * sizeof(T));
+    w->assign((size_t)((plain_rows_ + 63) / 64), 0);
+    if (plain_rows_ > 0 && EnsurePlainResident()) {
+      ++ips::stats().pred_launches;
+      ips::DeviceBuffer bm(w->size() * 8);
+      if (ips::ok(ips_plain_pred(plain_dev_.get(), plain_rows_, t, (ips_op)op, lits, n_lits,
+                                 (ips_semantics)IPS_PLAIN_SEMANTICS, bm.as<uint64_t>(), nullptr),
+                  "ips_plain_pred"))
+        bm.download(w->data(), w->size() * 8);
+    }
+    words = w;
+  }
+  const int64_t first = (int64_t)(data_ - plain_begin_) / ips_plain_stride(t);
+  ips::append_bits(b, *words, first, n, plain_rows_);
 }
 
 // ---- leaves of the predicate tree, simple-predicates.h:165-205 ----

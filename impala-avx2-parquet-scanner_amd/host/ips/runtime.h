@@ -30,6 +30,46 @@ inline bool ok(ips_status s, const char* where) {
   return false;
 }
 
+// Device work issued by the facade, for tests of its call pattern (the reference evaluates every
+// leaf once per 1024-row batch, hdfs-parquet-scanner.cc:1838; the facade evaluates a page once per
+// distinct predicate and serves the batches from that bitmap).
+struct FacadeStats {
+  long pred_launches = 0;   // whole-page predicate evaluations (FLE / dictionary / PLAIN)
+  long page_uploads = 0;    // host -> device copies of page payloads
+  long decode_launches = 0;
+};
+inline FacadeStats& stats() {
+  static thread_local FacadeStats s;
+  return s;
+}
+
+// Whole-page bitmaps of the predicates seen on a page, keyed by (op, constants): a BETWEEN is
+// Ge then Le per batch (simple-predicates.h:145-153), a conjunct list alternates even more leaves,
+// so one slot would evict itself on every call.  Small and linear: a page sees a handful of leaves.
+class PredCache {
+ public:
+  // words of the entry for (op, key bytes), or NULL
+  const std::vector<uint64_t>* find(int op, const void* key, size_t key_len) const {
+    for (const Entry& e : entries_)
+      if (e.op == op && e.key.size() == key_len && memcmp(e.key.data(), key, key_len) == 0) return &e.words;
+    return nullptr;
+  }
+  std::vector<uint64_t>* insert(int op, const void* key, size_t key_len) {
+    if (entries_.size() >= kMaxEntries) entries_.erase(entries_.begin());  // oldest out
+    entries_.emplace_back();
+    Entry& e = entries_.back();
+    e.op = op;
+    e.key.assign((const uint8_t*)key, (const uint8_t*)key + key_len);
+    return &e.words;
+  }
+  void clear() { entries_.clear(); }
+
+ private:
+  static const size_t kMaxEntries = 16;
+  struct Entry { int op; std::vector<uint8_t> key; std::vector<uint64_t> words; };
+  std::vector<Entry> entries_;
+};
+
 // Owns one device allocation.
 class DeviceBuffer {
  public:
@@ -59,6 +99,7 @@ class DeviceBuffer {
   template <typename T> T* as() const { return reinterpret_cast<T*>(p_); }
   size_t size() const { return n_; }
   bool upload(const void* h, size_t bytes) {
+    ++stats().page_uploads;
     return resize(bytes) && (bytes == 0 || ok(ips_memcpy_h2d(p_, h, bytes, nullptr), "ips_memcpy_h2d"));
   }
   bool download(void* h, size_t bytes) const {

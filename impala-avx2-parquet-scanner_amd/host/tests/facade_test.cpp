@@ -328,17 +328,18 @@ static void TestScanner() {
       row += batch;
     }
     CHECK(selected > 0);
-    if (!with_nullable) {  // one-launch program over all rows
+    {  // the whole conjunct list over all rows in one ips_eval_program call: REQUIRED, PLAIN and
+       // (with_nullable) the OPTIONAL dictionary column through the fused nullable leaf
       HdfsParquetScanner s2;
-      build(s2, false);
+      build(s2, with_nullable);
       std::vector<ExprContext*> ctxs2;
-      conjuncts(ctxs2, false);
+      conjuncts(ctxs2, with_nullable);
       std::vector<SimplePredicate*> roots2;
       CHECK(CreateSimplePredicates(&s2, ctxs2, &roots2));
       for (SimplePredicate* r : roots2) s2.AddSimplePredicate(r);
       std::vector<uint64_t> words;
       CHECK(s2.EvalSimplePredicatesFused(n, &words));
-      for (int i = 0; i < n; ++i) CHECK((bool)((words[(size_t)i >> 6] >> (i & 63)) & 1) == expect(i, false));
+      for (int i = 0; i < n; ++i) CHECK((bool)((words[(size_t)i >> 6] >> (i & 63)) & 1) == expect(i, with_nullable));
       for (ExprContext* c : ctxs2) delete c;
     }
     for (ExprContext* c : ctxs) delete c;
@@ -462,6 +463,109 @@ static void TestScannerMultiPage() {
   for (ExprContext* c : ctxs) delete c;
 }
 
+// The reference's call pattern -- every leaf once per 1024-row batch (hdfs-parquet-scanner.cc:1838)
+// -- must not turn into a device launch, an upload or a download per batch: a BETWEEN (And(Ge, Le),
+// simple-predicates.h:145-153) over a 2^20-row page is 2 whole-page evaluations, not 2048.
+static void TestCallPatternLaunchCounts() {
+  const int n = 1 << 20;
+  std::vector<int32_t> c0(n), c1(n), c2(n);
+  std::vector<bool> c1_null(n);
+  DictEncoder<int32_t> e0, e1;
+  for (int i = 0; i < n; ++i) {
+    c0[i] = (int32_t)(rnd() % 3000);
+    c1_null[i] = (rnd() % 9) == 0;
+    c1[i] = (int32_t)(rnd() % 200);
+    c2[i] = (int32_t)(rnd() % 100000);
+    e0.Put(c0[i]);
+    if (!c1_null[i]) e1.Put(c1[i]);
+  }
+  auto pages = [](DictEncoder<int32_t>& enc, std::vector<uint8_t>& dict, std::vector<uint8_t>& data) {
+    dict.resize((size_t)enc.dict_encoded_size() + 8);
+    enc.WriteDict(dict.data());
+    data.resize((size_t)4 << 20);
+    int len = enc.WriteData(data.data(), (int)data.size());
+    data.resize((size_t)len);
+  };
+  std::vector<uint8_t> d0, p0, d1, p1;
+  pages(e0, d0, p0);
+  pages(e1, d1, p1);
+  std::vector<uint8_t> defbuf((size_t)ips_fle_encoded_bytes(n, 1));
+  FleEncoder defenc(defbuf.data(), (int)defbuf.size(), 1);
+  for (int i = 0; i < n; ++i) defenc.Put(c1_null[i] ? 0u : 1u);
+  int32_t n_def_bytes = defenc.Flush();
+  std::vector<uint8_t> p1full(4 + (size_t)n_def_bytes + p1.size());
+  memcpy(p1full.data(), &n_def_bytes, 4);
+  memcpy(p1full.data() + 4, defbuf.data(), (size_t)n_def_bytes);
+  memcpy(p1full.data() + 4 + n_def_bytes, p1.data(), p1.size());
+  std::vector<uint8_t> plain((size_t)n * 4);
+  memcpy(plain.data(), c2.data(), plain.size());
+
+  // which: 0 REQUIRED dictionary column, 1 OPTIONAL dictionary column, 2 PLAIN column
+  for (int which = 0; which < 3; ++which) {
+    HdfsParquetScanner scanner;
+    const int lo = which == 0 ? 500 : which == 1 ? 20 : 60000, hi = which == 0 ? 1500 : which == 1 ? 120 : 1000;
+    if (which == 0) scanner.AddDictionaryColumn<int32_t>(d0.data(), e0.dict_encoded_size(), p0.data(), (int)p0.size(), n);
+    if (which == 1) scanner.AddDictionaryColumn<int32_t>(d1.data(), e1.dict_encoded_size(), p1full.data(), (int)p1full.size(), n, 1);
+    if (which == 2) scanner.AddPlainColumn<int32_t>(plain.data(), n);
+    SimplePredicate* between = scanner.Own(new AndOperate(scanner.Own(new GeOperate<int32_t>(0, lo)),
+                                                          scanner.Own(new LeOperate<int32_t>(0, hi))));
+    scanner.AddSimplePredicate(between);
+    const ips::FacadeStats before = ips::stats();
+    int64_t row = 0, bad = 0;
+    while (row < n) {
+      SkipBitset bs;
+      CHECK(scanner.EvalSimplePredicates(bs));
+      const int64_t batch = (int64_t)bs.size();
+      if (batch <= 0) break;
+      for (int64_t i = 0; i < batch; ++i) {
+        const int64_t r = row + i;
+        bool e;
+        if (which == 0) e = c0[r] >= lo && c0[r] <= hi;
+        else if (which == 1) e = !c1_null[r] && c1[r] >= lo && c1[r] <= hi;
+        else e = lo >= c2[r] && hi <= c2[r];  // PLAIN: the reference's operand order, literal OP x (quirk Q1)
+        if (bs[(size_t)i] != e) ++bad;
+      }
+      row += batch;
+    }
+    CHECK(row == n && bad == 0);
+    const ips::FacadeStats after = ips::stats();
+    // Ge + Le (+ def levels == max_def for the OPTIONAL column), each ONCE for the page
+    CHECK(after.pred_launches - before.pred_launches <= (which == 1 ? 3 : 2));
+    CHECK(after.decode_launches == before.decode_launches);
+    if (which == 2) CHECK(after.page_uploads - before.page_uploads == 1);  // the PLAIN page, once
+  }
+}
+
+// Truncated / corrupt data pages are refused instead of read out of bounds.
+static void TestTruncatedPages() {
+  DictEncoder<int32_t> e;
+  for (int i = 0; i < 200; ++i) e.Put(i % 17);
+  std::vector<uint8_t> dict((size_t)e.dict_encoded_size() + 8), data(4096);
+  e.WriteDict(dict.data());
+  int len = e.WriteData(data.data(), (int)data.size());
+  std::vector<uint8_t> page(4 + 32 + (size_t)len);
+  int32_t n_def = 32;
+  memcpy(page.data(), &n_def, 4);
+  memset(page.data() + 4, 0xFF, 32);
+  memcpy(page.data() + 36, data.data(), (size_t)len);
+  HdfsParquetScanner s;
+  CHECK(s.AddDictionaryColumn<int32_t>(dict.data(), e.dict_encoded_size(), page.data(), (int)page.size(), 200, 1) == 0);
+  CHECK(ips::sticky_status() == IPS_OK);
+  CHECK(s.AddDictionaryColumn<int32_t>(dict.data(), e.dict_encoded_size(), page.data(), 3, 200, 1) == -1);      // < 4 bytes
+  int32_t huge = 1 << 30;
+  memcpy(page.data(), &huge, 4);
+  CHECK(s.AddDictionaryColumn<int32_t>(dict.data(), e.dict_encoded_size(), page.data(), (int)page.size(), 200, 1) == -1);  // n_def_bytes > left
+  int32_t neg = -8;
+  memcpy(page.data(), &neg, 4);
+  CHECK(s.AddDictionaryColumn<int32_t>(dict.data(), e.dict_encoded_size(), page.data(), (int)page.size(), 200, 1) == -1);  // negative
+  memcpy(page.data(), &n_def, 4);
+  CHECK(s.AddDictionaryColumn<int32_t>(dict.data(), e.dict_encoded_size(), page.data(), 36, 200, 1) == -1);     // no width byte left
+  page[36] = 77;
+  CHECK(s.AddDictionaryColumn<int32_t>(dict.data(), e.dict_encoded_size(), page.data(), (int)page.size(), 200, 1) == -1);  // width 77
+  CHECK(ips::sticky_status() == IPS_ERR_INVALID_ARG);
+  ips::sticky_status() = IPS_OK;
+}
+
 // ips_eval_program straight through the C-ABI from a plain C++ process: an OR of two conjunctions
 // needs a temporary bitmap next to d_bitmap (stream-ordered allocation inside the call).
 static void TestProgramWithTemporaryBitmap() {
@@ -472,7 +576,7 @@ static void TestProgramWithTemporaryBitmap() {
   CHECK(da.upload(a.data(), (size_t)n * 4) && db.upload(b.data(), (size_t)n * 4));
   CHECK(ips_fle_encode(da.get(), 4, n, 12, ea.get(), nullptr) == IPS_OK);
   CHECK(ips_fle_encode(db.get(), 4, n, 6, eb.get(), nullptr) == IPS_OK);
-  ips_column cols[2] = {{IPS_COL_FLE, 12, 0, 0, ea.get()}, {IPS_COL_FLE, 6, 0, 0, eb.get()}};
+  ips_column cols[2] = {{IPS_COL_FLE, 12, 0, 0, ea.get(), nullptr, 0, 0, 0}, {IPS_COL_FLE, 6, 0, 0, eb.get(), nullptr, 0, 0, 0}};
   auto leaf = [](int col, ips_op op, uint64_t c) {
     ips_node nd;
     memset(&nd, 0, sizeof(nd));
@@ -489,7 +593,7 @@ static void TestProgramWithTemporaryBitmap() {
   const int64_t words = (n + 63) / 64;
   ips::DeviceBuffer bm((size_t)words * 8);
   const int n_prog = (int)(sizeof(prog) / sizeof(prog[0]));
-  const size_t ws_bytes = ips_program_workspace_bytes(prog, n_prog, n);
+  const size_t ws_bytes = ips_program_workspace_bytes(prog, n_prog, cols, 2, n);
   CHECK(ws_bytes >= (size_t)words * 8);  // (A and B) or (C and D) or ...: two bitmaps alive
   CHECK(ips_eval_program(prog, n_prog, cols, 2, n, bm.as<uint64_t>(), nullptr, nullptr) == IPS_ERR_INVALID_ARG);
   ips::DeviceBuffer ws(ws_bytes);
@@ -528,6 +632,8 @@ int main() {
   TestScanner();
   TestScannerMultiPage();
   TestProgramWithTemporaryBitmap();
+  TestCallPatternLaunchCounts();
+  TestTruncatedPages();
   CHECK(ips::sticky_status() == IPS_OK);
   printf("facade_test: %d checks, %d failed\n", g_checks, g_fail);
   return g_fail ? 1 : 0;

@@ -13,8 +13,10 @@
 //   Eq..In         non-advancing, append num_rows bits for rows p.. (fle-encoding.h:7962-8313).
 //                  The reference is called once per 1024-row batch (hdfs-parquet-scanner.cc:1838);
 //                  the facade evaluates the predicate for the WHOLE page in one ips_fle_pred
-//                  launch the first time a given (op, constants) is seen and serves later batches
-//                  from that bitmap -- the concatenation of batch bitmaps is identical.
+//                  launch the first time a given (op, constants) is seen on the page and serves
+//                  every later batch from that bitmap (a small cache keyed by (op, constants):
+//                  a BETWEEN is Ge then Le per batch, simple-predicates.h:145-153) -- the
+//                  concatenation of batch bitmaps is identical.
 // Differences kept on purpose: a trailing partial block (buffer_len not a multiple of
 // 8*bit_width) is ignored rather than over-read.
 #pragma once
@@ -69,6 +71,7 @@ class FleDecoder {
   int64_t cursor() const { return s_ ? s_->cursor : 0; }
   int64_t rows_in_buffer() const { return s_ ? s_->rows : 0; }
   const void* device_blocks() const { return s_ ? s_->enc.get() : nullptr; }
+  bool usable() const { return s_ && s_->usable; }
 
  private:
   struct State {
@@ -78,9 +81,7 @@ class FleDecoder {
     ips::DeviceBuffer enc;
     bool decoded = false;
     std::vector<uint32_t> values;       // whole page, filled by one ips_fle_decode
-    bool have_pred = false;             // bitmap of the last (op, constants) over the whole page
-    int pred_op = 0;
-    std::vector<uint64_t> pred_consts, pred_words;
+    ips::PredCache preds;               // whole-page bitmaps per (op, constants)
   };
 
   bool EnsureDecoded() {
@@ -89,6 +90,7 @@ class FleDecoder {
     s_->values.resize((size_t)s_->rows);
     if (s_->rows > 0) {
       ips::DeviceBuffer out((size_t)s_->rows * 4);
+      ++ips::stats().decode_launches;
       if (!ips::ok(ips_fle_decode(s_->enc.get(), s_->rows, s_->bw, out.get(), 4, nullptr), "ips_fle_decode") ||
           !out.download(s_->values.data(), (size_t)s_->rows * 4))
         return false;
@@ -109,22 +111,20 @@ class FleDecoder {
 
   void Pred(ips_op op, int64_t num_rows, SkipBitset& out, const uint64_t* consts, int n) {
     if (!s_ || num_rows <= 0) return;
-    const bool hit = s_->have_pred && s_->pred_op == (int)op && (int)s_->pred_consts.size() == n &&
-                     std::equal(consts, consts + n, s_->pred_consts.begin());
-    if (!hit) {
-      s_->have_pred = false;
-      s_->pred_words.assign((size_t)((s_->rows + 63) / 64), 0);
+    const std::vector<uint64_t>* words = s_->preds.find((int)op, consts, (size_t)n * 8);
+    if (!words) {
+      std::vector<uint64_t>* w = s_->preds.insert((int)op, consts, (size_t)n * 8);
+      w->assign((size_t)((s_->rows + 63) / 64), 0);
       if (s_->usable && s_->rows > 0) {
-        ips::DeviceBuffer bm((size_t)s_->pred_words.size() * 8);
+        ++ips::stats().pred_launches;
+        ips::DeviceBuffer bm((size_t)w->size() * 8);
         if (ips::ok(ips_fle_pred(s_->enc.get(), s_->rows, s_->bw, op, consts, n,
                                  bm.as<uint64_t>(), nullptr), "ips_fle_pred"))
-          bm.download(s_->pred_words.data(), s_->pred_words.size() * 8);
+          bm.download(w->data(), w->size() * 8);
       }
-      s_->pred_op = (int)op;
-      s_->pred_consts.assign(consts, consts + n);
-      s_->have_pred = true;
+      words = w;
     }
-    ips::append_bits(out, s_->pred_words, s_->cursor, num_rows, s_->rows);
+    ips::append_bits(out, *words, s_->cursor, num_rows, s_->rows);
   }
 
   std::shared_ptr<State> s_;

@@ -27,6 +27,37 @@ def stripe_bounds(n_rows, world, rank):
     return row0, min(row0 + s, n_rows)
 
 
+def cyclic_pieces(n_rows, world, rank, n_chunks):
+    """Block-cyclic stripes for an exchange that overlaps the scan INSIDE one step (SURVEY 8e:
+    "chunk the stripe ... overlap gather of chunk i with scan of chunk i+1").
+
+    The column is cut into n_chunks * world pieces of piece_rows rows (a multiple of ALIGN_ROWS);
+    rank r owns pieces r, world + r, 2*world + r, ...  All ranks' i-th pieces are adjacent in the
+    column, so all-gathering the bitmap words of chunk i (piece_rows / 64 words per rank) fills
+    words [i*world*pw, (i+1)*world*pw) of the global bitmap in natural row order: the gathered
+    bitmap is bit-identical to a single-GPU scan and chunk i can be on the wire while chunk i+1
+    is still being scanned.  Returns (piece_rows, [(row0, row1)] * n_chunks); pieces beyond the
+    data are empty (row0 == row1)."""
+    piece_rows = stripe_rows(n_rows, world * n_chunks)
+    pieces = []
+    for i in range(n_chunks):
+        row0 = min((i * world + rank) * piece_rows, n_rows)
+        pieces.append((row0, min(row0 + piece_rows, n_rows)))
+    return piece_rows, pieces
+
+
+def allgather_chunk(local_words, full_words, chunk, piece_words, world, group=None):
+    """All-gather chunk `chunk` of every rank into its place of the global bitmap (torch.distributed
+    form of ips_allgather_bitmap; used by the CPU tests with gloo).  local_words: this rank's
+    piece_words words of the chunk (zero-padded when the piece is short or empty)."""
+    send = local_words
+    if send.numel() != piece_words:
+        send = torch.zeros(piece_words, dtype=local_words.dtype, device=local_words.device)
+        send[:local_words.numel()] = local_words
+    dst = full_words[chunk * world * piece_words:(chunk + 1) * world * piece_words]
+    return dist.all_gather_into_tensor(dst, send.contiguous(), group=group, async_op=True)
+
+
 def stripe_word_slice(enc_words, bit_width, n_rows, world, rank):
     """The encoded words (FLE blocks) of this rank's stripe: w words per 64-row block."""
     row0, row1 = stripe_bounds(n_rows, world, rank)

@@ -113,6 +113,24 @@ ips_status ips_fle_pred(const void* d_enc, int64_t n_rows, int bit_width, ips_op
                         const uint64_t* consts, int n_consts, uint64_t* d_bitmap,
                         ips_stream stream);
 
+/* Predicate on an OPTIONAL (nullable) column: ColumnReader<T>::Eq..In's dictionary branch,
+ * hdfs-parquet-scanner.cc:338-345 -- fle_def_levels_->Eq(n, bits, max_def_level), the data predicate
+ * over the bits.count() non-NULL values, IntersectBitset (:326-331) -- without the host ever
+ * learning the non-NULL count.  bit r of d_bitmap = row r is not NULL and its value passes.
+ *   d_def_levels   FLE blocks of the n_rows definition levels, width def_bit_width
+ *                  (= Log2(max_def_level + 1), writer :387-399); width 1 / max_def 1 is read as the
+ *                  NOT-NULL bits directly
+ *   d_data_enc     FLE blocks of the non-NULL rows' values only; n_data_rows = rows this buffer
+ *                  holds (any upper bound of the non-NULL count that the buffer covers, e.g.
+ *                  64 * blocks; rows beyond it count as not selected)
+ *   d_workspace    ips_nullable_workspace_bytes(n_rows) bytes, 16-byte aligned
+ * Launch-only (4 launches at most: [levels == max_def], tile ranks, data predicate, expand). */
+size_t ips_nullable_workspace_bytes(int64_t n_rows);
+ips_status ips_fle_pred_nullable(const void* d_def_levels, int def_bit_width, int max_def_level,
+                                 int64_t n_rows, const void* d_data_enc, int64_t n_data_rows,
+                                 int bit_width, ips_op op, const uint64_t* consts, int n_consts,
+                                 uint64_t* d_bitmap, void* d_workspace, ips_stream stream);
+
 /* Fused scan of one FLE column chunk: predicate -> bitmap, plus late materialisation of the
  * selected rows in the same pass over the encoded bytes (EvalSimplePredicates + ReadValue(skip),
  * hdfs-parquet-scanner.cc:1837-1865, 1134-1181, 1006-1027; FleDecoder::Get(val, skip)
@@ -230,6 +248,14 @@ ips_status ips_dict_pred(const ips_dict* dict, const void* d_codes_enc, int64_t 
                          int bit_width, ips_op op, const void* literals, int n_literals,
                          uint64_t* d_bitmap, ips_stream stream);
 
+/* ips_dict_pred on an OPTIONAL column (see ips_fle_pred_nullable): literals are translated to
+ * codes first; a translation that says "all rows" selects every NON-NULL row. */
+ips_status ips_dict_pred_nullable(const ips_dict* dict, const void* d_def_levels,
+                                  int def_bit_width, int max_def_level, int64_t n_rows,
+                                  const void* d_codes_enc, int64_t n_data_rows, int bit_width,
+                                  ips_op op, const void* literals, int n_literals,
+                                  uint64_t* d_bitmap, void* d_workspace, ips_stream stream);
+
 /* DictDecoder<T>::GetValue x n, dict-encoding.h:310-319: d_out[r] = dict[code_r] (sizeof(T)
  * bytes each; int8/int16 as 1/2 bytes).  *d_bad_index (int32, may be NULL) is set non-zero if a
  * code >= num_entries was met (the reference returns false, :316). */
@@ -311,11 +337,16 @@ typedef enum { IPS_NODE_LEAF = 0, IPS_NODE_AND = 1, IPS_NODE_OR = 2 } ips_node_k
 typedef enum { IPS_COL_FLE = 0, IPS_COL_PLAIN = 1 } ips_col_encoding;
 
 typedef struct {
-  int32_t encoding;      /* ips_col_encoding */
-  int32_t bit_width;     /* FLE: 1..32 */
-  int32_t type;          /* PLAIN: ips_type */
+  int32_t encoding;         /* ips_col_encoding */
+  int32_t bit_width;        /* FLE: 1..32 */
+  int32_t type;             /* PLAIN: ips_type */
+  int32_t max_def_level;    /* 0 = REQUIRED column; > 0 = OPTIONAL (FLE encoding only: the reference's
+                               PLAIN branch ignores definition levels, hdfs-parquet-scanner.cc:346-348) */
+  const void* d_data;       /* FLE blocks or PLAIN page (OPTIONAL: of the non-NULL rows only) */
+  const void* d_def_levels; /* OPTIONAL: FLE blocks of the n_rows definition levels */
+  int32_t def_bit_width;    /* OPTIONAL: Log2(max_def_level + 1) */
   int32_t reserved;
-  const void* d_data;    /* FLE blocks or PLAIN page */
+  int64_t n_data_rows;      /* OPTIONAL: rows d_data holds (see ips_fle_pred_nullable) */
 } ips_column;
 
 /* Postfix program: leaves push a bitmap, AND/OR pop two and push one (AndOperate / OrOperate,
@@ -330,11 +361,13 @@ typedef struct {
 
 #define IPS_PROGRAM_MAX_NODES 32
 #define IPS_PROGRAM_MAX_COLS 8
-/* Trees that keep more than one bitmap alive (an OR of ANDs) park the extra bitmaps in d_workspace:
- * ips_program_workspace_bytes(nodes, n_nodes, n_rows) bytes, 16-byte aligned; 0 for a conjunct
- * chain, and then d_workspace may be NULL.  The call allocates nothing and only launches, so it
+/* Trees that keep more than one bitmap alive (an OR of ANDs) and leaves on OPTIONAL columns (rank
+ * tables, the data rows' bitmap) park their temporaries in d_workspace:
+ * ips_program_workspace_bytes(...) bytes, 16-byte aligned; 0 for a conjunct chain over REQUIRED
+ * columns, and then d_workspace may be NULL.  The call allocates nothing and only launches, so it
  * can be captured into a hipGraph together with its workspace. */
-size_t ips_program_workspace_bytes(const ips_node* nodes, int n_nodes, int64_t n_rows);
+size_t ips_program_workspace_bytes(const ips_node* nodes, int n_nodes, const ips_column* cols,
+                                   int n_cols, int64_t n_rows);
 ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const ips_column* cols, int n_cols,
                             int64_t n_rows, uint64_t* d_bitmap, void* d_workspace,
                             ips_stream stream);

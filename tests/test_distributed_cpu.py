@@ -73,6 +73,42 @@ def _worker_q6(rank, world, port, n_rows, ret):
     dist.destroy_process_group()
 
 
+def _worker_cyclic(rank, world, port, n_rows, n_chunks, ret):
+    """Block-cyclic pieces + one all-gather per chunk (issued asynchronously, as bench.py overlaps
+    them with the next chunk's scan): the gathered bitmap is in natural row order."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import __graft_entry__ as g
+    from oracle import oracle as O
+    pkg = g.load_package()
+    sharding, synth = pkg.sharding, pkg.synth
+    bw = 9
+    c = synth.lt_constant(bw)
+    piece_rows, pieces = sharding.cyclic_pieces(n_rows, world, rank, n_chunks)
+    pw = piece_rows // 64
+    full = torch.zeros(n_chunks * world * pw, dtype=torch.int64)
+    works = []
+    for i, (row0, row1) in enumerate(pieces):
+        m = row1 - row0
+        local = np.zeros(0, np.uint64)
+        if m > 0:
+            enc = O.fle_encode(synth.column_u32(synth.SEED_HEADLINE, m, bw, start=row0), bw)
+            local = O.fle_pred(enc, m, bw, O.OP_LT, c)
+        works.append(sharding.allgather_chunk(torch.from_numpy(local.view(np.int64).copy()), full, i, pw, world))
+    for w in works:
+        w.wait()
+    whole = O.fle_pred(O.fle_encode(synth.column_u32(synth.SEED_HEADLINE, n_rows, bw), bw), n_rows, bw, O.OP_LT, c)
+    got = full.numpy().view(np.uint64)
+    ok = np.array_equal(got[:len(whole)], whole) and not got[len(whole):].any()
+    t = torch.tensor([int(ok)])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        ret.put(bool(t.item()))
+    dist.destroy_process_group()
+
+
 def _run_world(target, args, world=2):
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
@@ -83,6 +119,30 @@ def _run_world(target, args, world=2):
         p.join(120)
         assert p.exitcode == 0
     return ret.get(timeout=10)
+
+
+@pytest.mark.parametrize("n_rows,n_chunks", [(2048 * 40 + 13, 8), (5000, 8), (2048 * 16, 4)])
+def test_block_cyclic_pieces_chunked_gather(n_rows, n_chunks):
+    port = 33500 + (os.getpid() + n_rows) % 2000
+    assert _run_world(_worker_cyclic, (port, n_rows, n_chunks)) is True
+
+
+def test_cyclic_piece_geometry():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    sh = g.load_package().sharding
+    for n in (1, 2049, 2048 * 64, 600_037_902):
+        for world in (1, 2, 4, 8):
+            for chunks in (1, 8):
+                pr, _ = sh.cyclic_pieces(n, world, 0, chunks)
+                assert pr % 2048 == 0 and pr * world * chunks >= n
+                cover = []
+                for i in range(chunks):
+                    for r in range(world):
+                        cover.append(sh.cyclic_pieces(n, world, r, chunks)[1][i])
+                assert cover[0][0] == 0 and max(b for _, b in cover) == n
+                for (a0, a1), (b0, b1) in zip(cover, cover[1:]):   # natural order, no gaps
+                    assert a1 == b0 or (b0 == b1 == n)
 
 
 @pytest.mark.parametrize("n_rows", [2048 * 5 + 77, 1500, 2048 * 4])

@@ -497,8 +497,8 @@ def test_entry_points_capture_into_a_graph(capi, O):
     plist = capi.make_page_list(pages)
     # the tree keeps two bitmaps alive: its temporary lives in a caller workspace, so the captured
     # launches are the per-operand plan (no hidden allocation, nothing library-owned baked in)
-    assert capi.program_workspace_bytes(chain, n) == 0
-    need = capi.program_workspace_bytes(tree, n)
+    assert capi.program_workspace_bytes(chain, cols, n) == 0
+    need = capi.program_workspace_bytes(tree, cols, n)
     assert need >= ((n + 63) // 64) * 8
     ws_tree = torch.empty(need, dtype=torch.uint8, device="cuda")
     with pytest.raises(capi.IpsError):      # a tree that needs a workspace does not get one

@@ -1,0 +1,186 @@
+"""Predicates on OPTIONAL (nullable) columns through the fused leaf (ips_fle_pred_nullable /
+ips_dict_pred_nullable) against the reference's three steps restated by the oracle
+(hdfs-parquet-scanner.cc:338-345: fle_def_levels_->Eq, data predicate over bits.count() values,
+IntersectBitset :326-331)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_words(a):
+    a = np.ascontiguousarray(a)
+    if a.size == 0:
+        return torch.zeros(2, dtype=torch.int64, device="cuda")
+    return torch.from_numpy(a.view(np.int64).copy()).cuda()
+
+
+def words(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def bits_of(w, n):
+    return np.unpackbits(np.ascontiguousarray(w).view(np.uint8), bitorder="little")[:n].astype(bool)
+
+
+def oracle_leaf(O, defs, def_bw, max_def, n, data_enc, k, bw, op, consts):
+    nonnull = O.fle_pred(defs, n, def_bw, O.OP_EQ, max_def)
+    assert int(bits_of(nonnull, n).sum()) == k
+    sub = O.fle_pred(data_enc, k, bw, op, consts) if k else np.zeros(1, np.uint64)
+    return O.bitmap_expand(nonnull, sub, n)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 4097, 70001, 262144, 262145, 3 * 262144 + 77, 1 << 21])
+@pytest.mark.parametrize("null_frac", [0.0, 0.1, 0.5, 0.97, 1.0])
+def test_nullable_leaf_vs_oracle(capi, O, n, null_frac):
+    rng = np.random.default_rng(n * 7 + int(null_frac * 100))
+    bw = int(rng.integers(1, 17))
+    is_set = rng.random(n) >= null_frac
+    if null_frac == 0.0:
+        is_set[:] = True
+    k = int(is_set.sum())
+    vals = rng.integers(0, 1 << bw, max(k, 1)).astype(np.uint32)[:k]
+    defs = O.fle_encode(is_set.astype(np.uint32), 1)
+    enc = O.fle_encode(vals, bw) if k else np.zeros(2, np.uint64)
+    d_defs, d_enc = dev_words(defs), dev_words(enc)
+    n_data = ((k + 63) // 64) * 64          # what the host knows: blocks * 64
+    c = int(rng.integers(0, 1 << bw))
+    for op, consts in ((O.OP_LT, c), (O.OP_GE, c), (O.OP_EQ, int(vals[0]) if k else 0),
+                       (O.OP_IN, [c, (c + 1) % (1 << bw), 0])):
+        got = words(capi.fle_pred_nullable(d_defs, 1, 1, n, d_enc, n_data, bw, op, consts))
+        exp = oracle_leaf(O, defs, 1, 1, n, enc, k, bw, op, consts)
+        assert np.array_equal(got, exp), (n, null_frac, bw, op)
+    # row-model check of one of them
+    got = bits_of(words(capi.fle_pred_nullable(d_defs, 1, 1, n, d_enc, n_data, bw, O.OP_LT, c)), n)
+    expect = np.zeros(n, bool)
+    expect[np.flatnonzero(is_set)[vals < c]] = True
+    assert np.array_equal(got, expect)
+
+
+def test_nullable_leaf_wider_definition_levels(capi, O):
+    """max_def_level 2 (a nested OPTIONAL): levels are 2 bits wide, NOT NULL <=> level == 2."""
+    rng = np.random.default_rng(5)
+    n, bw = 100003, 9
+    levels = rng.integers(0, 3, n).astype(np.uint32)
+    is_set = levels == 2
+    k = int(is_set.sum())
+    vals = rng.integers(0, 1 << bw, k).astype(np.uint32)
+    defs, enc = O.fle_encode(levels, 2), O.fle_encode(vals, bw)
+    got = words(capi.fle_pred_nullable(dev_words(defs), 2, 2, n, dev_words(enc), k, bw, O.OP_GT, 300))
+    assert np.array_equal(got, oracle_leaf(O, defs, 2, 2, n, enc, k, bw, O.OP_GT, 300))
+
+
+def test_nullable_leaf_constants_outside_the_domain_and_short_data(capi, O):
+    rng = np.random.default_rng(6)
+    n, bw = 50000, 6
+    is_set = rng.random(n) < 0.7
+    k = int(is_set.sum())
+    vals = rng.integers(0, 1 << bw, k).astype(np.uint32)
+    defs, enc = O.fle_encode(is_set.astype(np.uint32), 1), O.fle_encode(vals, bw)
+    d_defs, d_enc = dev_words(defs), dev_words(enc)
+    nonnull = O.fle_pred(defs, n, 1, O.OP_EQ, 1)
+    # LT 2^w: every NON-NULL row; GT 2^w: none (quirk Q6 stance: unsigned SQL meaning)
+    assert np.array_equal(words(capi.fle_pred_nullable(d_defs, 1, 1, n, d_enc, k, bw, O.OP_LT, 1 << bw)), nonnull)
+    assert not words(capi.fle_pred_nullable(d_defs, 1, 1, n, d_enc, k, bw, O.OP_GT, 1 << bw)).any()
+    # a data buffer shorter than the NOT-NULL count: the rows beyond it are not selected
+    short = (k // 2 // 64) * 64
+    got = bits_of(words(capi.fle_pred_nullable(d_defs, 1, 1, n, d_enc, short, bw, O.OP_GE, 0)), n)
+    expect = np.zeros(n, bool)
+    expect[np.flatnonzero(is_set)[:short]] = True
+    assert np.array_equal(got, expect)
+    with pytest.raises(capi.IpsError):
+        capi.fle_pred_nullable(d_defs, 1, 3, n, d_enc, k, bw, O.OP_LT, 3)   # max_def 3 in 1 bit
+
+
+@pytest.mark.parametrize("type_name", ["T_INT32", "T_INT64", "T_DOUBLE"])
+def test_nullable_dictionary_leaf(capi, O, type_name):
+    """ColumnReader<T>::Lt/Ge/In on an OPTIONAL dictionary page, literals translated to codes."""
+    t = getattr(O, type_name)
+    npt = O.NP_TYPES[t]
+    rng = np.random.default_rng(40 + t)
+    n = 300007
+    is_set = rng.random(n) < 0.85
+    k = int(is_set.sum())
+    pool = np.unique(rng.integers(-5000, 5000, 700)).astype(npt)
+    data_vals = pool[rng.integers(0, len(pool), k)]
+    defs = O.fle_encode(is_set.astype(np.uint32), 1)
+    d, dict_page, codes = O.dict_build(data_vals, t)
+    page = O.dict_write_data(codes, len(d))
+    bw, blocks = int(page[0]), np.frombuffer(page[1:].tobytes(), dtype=np.uint64)
+    dd = capi.Dict(dict_page, t)
+    d_defs, d_blocks = dev_words(defs), dev_words(blocks)
+    n_data = (len(blocks) // bw) * 64
+    lit = npt(pool[len(pool) // 3])
+    cases = [(O.OP_LT, lit, data_vals < lit), (O.OP_GE, lit, data_vals >= lit),
+             (O.OP_EQ, lit, data_vals == lit), (O.OP_LT, npt(10 ** 6), np.ones(k, bool)),
+             (O.OP_GT, npt(10 ** 6), np.zeros(k, bool)),
+             (O.OP_IN, np.array([pool[1], pool[5], 777777], npt), np.isin(data_vals, [pool[1], pool[5]]))]
+    for op, lits, data_truth in cases:
+        got = bits_of(words(dd.pred_nullable(d_defs, 1, 1, n, d_blocks, n_data, bw, op, lits)), n)
+        expect = np.zeros(n, bool)
+        expect[np.flatnonzero(is_set)[data_truth]] = True
+        assert np.array_equal(got, expect), (type_name, op)
+    dd.close()
+
+
+def test_nullable_leaf_2p28_rows_properties(capi, ips):
+    """Full size (2^28 rows, w = 12, 10 % NULLs): against torch on the raw columns."""
+    n, bw = 1 << 28, 12
+    dev = torch.device("cuda")
+    nn = capi.synth_u32(0x5EED0D1, n, 32)
+    is_set = (nn.to(torch.int64) & 0xFFFFFFFF) >= int(0.1 * (1 << 32))
+    del nn
+    defs = capi.fle_encode(is_set.to(torch.int32), 1)
+    k = int(is_set.sum().item())
+    vals = capi.synth_u32(0x5EED0D2, k, bw)
+    enc = capi.fle_encode(vals, bw)
+    ws = capi.nullable_workspace(n, dev)
+    bm = capi.fle_pred_nullable(defs, 1, 1, n, enc, ((k + 63) // 64) * 64, bw, capi.OP_LT, 409, workspace=ws)
+    sel_rows = torch.zeros(n, dtype=torch.bool, device=dev)
+    sel_rows[is_set] = vals < 409
+    assert capi.bitmap_count(bm, n) == int(sel_rows.sum().item())
+    w = sel_rows.view(-1, 64).to(torch.int64)
+    packed = (w << torch.arange(64, device=dev, dtype=torch.int64)).sum(dim=1)
+    assert torch.equal(packed, bm)
+
+
+def test_program_with_optional_columns(capi, O):
+    """ips_eval_program over REQUIRED and OPTIONAL columns: leaves on an OPTIONAL column go through
+    the nullable leaf (data predicate + expand, combined into the plan's bitmaps), a BETWEEN on it
+    in one pass; NULL rows never pass a leaf (SQL: NULL compared with anything is not true)."""
+    rng = np.random.default_rng(99)
+    n = 300001
+    a = rng.integers(0, 1 << 12, n).astype(np.uint32)                 # REQUIRED w=12
+    b_set = rng.random(n) < 0.8                                        # OPTIONAL w=7
+    b_vals = rng.integers(0, 1 << 7, int(b_set.sum())).astype(np.uint32)
+    c_set = rng.random(n) < 0.5                                        # OPTIONAL w=3, levels 2 bits wide
+    c_levels = np.where(c_set, 2, rng.integers(0, 2, n)).astype(np.uint32)
+    c_vals = rng.integers(0, 1 << 3, int(c_set.sum())).astype(np.uint32)
+    b_full = np.zeros(n, np.int64) - 1
+    b_full[b_set] = b_vals
+    c_full = np.zeros(n, np.int64) - 1
+    c_full[c_set] = c_vals
+    ea = dev_words(O.fle_encode(a, 12))
+    eb, db = dev_words(O.fle_encode(b_vals, 7)), dev_words(O.fle_encode(b_set.astype(np.uint32), 1))
+    ec, dc = dev_words(O.fle_encode(c_vals, 3)), dev_words(O.fle_encode(c_levels, 2))
+    cols = [capi.fle_column(ea, 12),
+            capi.nullable_fle_column(db, 1, 1, eb, 7, ((len(b_vals) + 63) // 64) * 64),
+            capi.nullable_fle_column(dc, 2, 2, ec, 3, len(c_vals))]
+    L, AND, OR = capi.leaf, capi.and_node, capi.or_node
+    nn_b, nn_c = b_full >= 0, c_full >= 0
+    cases = [
+        ([L(1, O.OP_LT, 40)], nn_b & (b_full < 40)),
+        ([L(1, O.OP_GE, 20), L(1, O.OP_LE, 90), AND()], nn_b & (b_full >= 20) & (b_full <= 90)),
+        ([L(0, O.OP_LT, 2000), L(1, O.OP_GE, 64), AND(), L(2, O.OP_EQ, 5), AND()],
+         (a < 2000) & nn_b & (b_full >= 64) & nn_c & (c_full == 5)),
+        ([L(0, O.OP_LT, 300), L(1, O.OP_IN, [1, 2, 3, 100]), OR(), L(2, O.OP_GT, 3), L(0, O.OP_GE, 4000), AND(), OR()],
+         (a < 300) | (nn_b & np.isin(b_full, [1, 2, 3, 100])) | (nn_c & (c_full > 3) & (a >= 4000))),
+    ]
+    for nodes, truth in cases:
+        assert capi.program_workspace_bytes(nodes, cols, n) > 0
+        got = bits_of(words(capi.eval_program(nodes, cols, n)), n)
+        assert np.array_equal(got, truth)
+    # the leaf alone agrees with the stand-alone entry point
+    solo = capi.eval_program([L(2, O.OP_LE, 4)], cols, n)
+    assert torch.equal(solo, capi.fle_pred_nullable(dc, 2, 2, n, ec, len(c_vals), 3, O.OP_LE, 4))
