@@ -26,7 +26,6 @@ import __graft_entry__ as entry  # noqa: E402
 METRIC = "decoded+filtered rows/sec and HBM GB/s vs roofline, int32 FLE @10% sel"
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 N_CHUNKS = int(os.environ.get("IPS_BENCH_CHUNKS", "8"))  # exchange granularity inside one step (N > 1)
-SCAN_STREAMS = int(os.environ.get("IPS_BENCH_SCAN_STREAMS", "2"))  # chunk launches alternate between streams
 
 
 def parse():
@@ -367,53 +366,35 @@ def main():
     outputs = capi.alloc_scan_outputs(n, dev)
     words = n // 64
     stream = torch.cuda.current_stream()
-    comm_stream = torch.cuda.Stream() if gather else None
-    # consecutive kernels of ONE stream never overlap (every dispatch waits for the previous one to
-    # drain), so a chunked step would pay a ramp-up and a tail per chunk; chunk launches therefore
-    # alternate between scan streams and the tail of chunk i overlaps the start of chunk i+1
-    scan_streams = [torch.cuda.Stream() for _ in range(SCAN_STREAMS)] if gather and SCAN_STREAMS > 1 else None
-    # double-buffered bitmaps: step s+1 scans into set (s+1)&1 while the gathers of step s still
-    # read set s&1; a set is reused only after the gathers of two steps ago have finished
-    local_bm = [outputs[0], torch.empty_like(outputs[0])] if gather else [outputs[0]]
-    full_bm = [torch.empty(words * world, dtype=torch.int64, device=dev) for _ in range(2)] if gather else None
-    gathered = [None, None]  # event: all gathers of the last step that used set k are done
+    comm_stream = torch.cuda.Stream() if gather else None  # (the Q6 leg's exchange stream)
+    # N > 1: one C call per step (ips_fle_scan_allgather) issues the chunk scans on `stream` and the
+    # all-gather of every finished chunk on the communicator's own stream; the next step first
+    # waits (stream-side, ips_comm_join) until the previous step's gathers have read the buffers.
+    local_bm = outputs[0]
+    full_bm = torch.empty(words * world, dtype=torch.int64, device=dev) if gather else None
 
     def step(s, bracket=None):
-        k = s & 1 if gather else 0
-        if gather and gathered[k] is not None:
-            stream.wait_event(gathered[k])
+        if gather:
+            comm.join(stream)
         if bracket:
             bracket[0].record(stream)
-        if scan_streams:
-            fork = stream.record_event()
-            for ss in scan_streams:
-                ss.wait_event(fork)
-        for i in range(n_chunks):
-            outs = (local_bm[k][i * words_c:], outputs[1][i * rows_c:], outputs[2][i * rows_c // 2048:])
-            ss = scan_streams[i % len(scan_streams)] if scan_streams else stream
-            capi.fle_scan(enc[i * enc_words_c:(i + 1) * enc_words_c], rows_c, bw, capi.OP_LT, c, outputs=outs,
-                          stream=ss)
-            if gather:
-                done = ss.record_event()
-                comm_stream.wait_event(done)
-                capi._ck(capi.lib().ips_allgather_bitmap(
-                    comm.h, C.c_void_p(local_bm[k][i * words_c:].data_ptr()), C.c_int64(words_c),
-                    C.c_void_p(full_bm[k][i * world * words_c:].data_ptr()), C.c_void_p(comm_stream.cuda_stream)))
-        if scan_streams:
-            for ss in scan_streams:
-                stream.wait_event(ss.record_event())
+        if gather:
+            comm.fle_scan_allgather(enc, n, bw, capi.OP_LT, c, n_chunks, local_bm, outputs[1], outputs[2],
+                                    full_bm, stream=stream)
+        else:
+            capi.fle_scan(enc, n, bw, capi.OP_LT, c, outputs=outputs)
         if bracket:
             bracket[1].record(stream)
-        if gather:
-            gathered[k] = comm_stream.record_event()
 
     def drain():
+        if gather:
+            comm.join(stream)
         torch.cuda.synchronize()
 
     for s in range(max(args.warmup, 1)):
         step(s)
     drain()
-    bitmap, bvals, counts = local_bm[(max(args.warmup, 1) - 1) & 1 if gather else 0], outputs[1], outputs[2]
+    bitmap, bvals, counts = local_bm, outputs[1], outputs[2]
     n_sel = int(counts.to(torch.int64).sum().item())
     check = None
     if rank == 0:
@@ -468,19 +449,18 @@ def main():
         kern_ms = sorted(a.elapsed_time(b) for a, b in single)
 
     if gather:  # bit-identity of the exchange
-        for k in range(min(2, args.steps)):
-            for i in range(n_chunks):  # piece (i, rank) of the gathered bitmap is this rank's chunk i
-                g0 = (i * world + rank) * words_c
-                assert torch.equal(full_bm[k][g0:g0 + words_c], local_bm[k][i * words_c:(i + 1) * words_c]), \
-                    "gathered bitmap differs from the local chunk"
-        chk = full_bm[0].sum().reshape(1).clone()  # every rank holds the same gathered words
+        for i in range(n_chunks):  # piece (i, rank) of the gathered bitmap is this rank's chunk i
+            g0 = (i * world + rank) * words_c
+            assert torch.equal(full_bm[g0:g0 + words_c], local_bm[i * words_c:(i + 1) * words_c]), \
+                "gathered bitmap differs from the local chunk"
+        chk = full_bm.sum().reshape(1).clone()  # every rank holds the same gathered words
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert int(lo.item()) == int(hi.item()), "ranks disagree on the gathered bitmap"
         if rank == 0:  # natural order: words of global rows [0, 2^20) are rank 0's first words
             n1 = min(rows_c, 1 << 20)
-            assert np.array_equal(full_bm[0][:n1 // 64].cpu().numpy().view(np.uint64), bm_ref)
+            assert np.array_equal(full_bm[:n1 // 64].cpu().numpy().view(np.uint64), bm_ref)
 
     # ---- configs[4] sharded: the Q6 conjunction over block-cyclic stripes + chunked gather ------
     q6_sharded = None
@@ -618,8 +598,8 @@ def main():
             "rows_per_gpu": n, "bit_width": bw, "predicate": f"LT {c}",
             "selectivity": round(n_sel / n, 5), "batch_rows": capi.BATCH_ROWS,
             "parallelism": (f"{world} ranks, block-cyclic row stripes ({n_chunks} chunks of {rows_c} rows per rank "
-                            "and step); ips_allgather_bitmap (RCCL) of chunk i on its own stream while chunk "
-                            "i+1 is scanned; gathered bitmap in natural row order"
+                            "and step, one ips_fle_scan_allgather call); RCCL all-gather of chunk i on the "
+                            "communicator's stream while chunk i+1 is scanned; gathered bitmap in natural row order"
                             if gather else "single GPU"),
         },
         "roofline": roofline, "cpu_baseline": cpu,

@@ -47,6 +47,7 @@ SYMBOLS = [
     "ips_expand_workspace_bytes", "ips_bitmap_expand",
     "ips_eval_program", "ips_synth_splitmix_u32",
     "ips_comm_unique_id", "ips_comm_init", "ips_comm_destroy", "ips_allgather_bitmap",
+    "ips_fle_scan_allgather", "ips_comm_join",
 ]
 
 
@@ -578,6 +579,17 @@ class Comm:
         _ck(lib().ips_allgather_bitmap(self.h, _ptr(local_words), C.c_int64(local_words.numel()),
                                        _ptr(out), _stream(stream)))
         return out
+
+    def fle_scan_allgather(self, enc, n_rows, bw, op, values, n_chunks, local_bitmap, bvals, counts,
+                           all_bitmap, stream=None):
+        """One step of the sharded scan: chunked scan + overlapped all-gather (one C call)."""
+        keep, p, k = _consts(values)
+        _ck(lib().ips_fle_scan_allgather(self.h, _ptr(enc), C.c_int64(n_rows), bw, op, p, k, n_chunks,
+                                         _ptr(local_bitmap), _ptr(bvals), _ptr(counts), _ptr(all_bitmap),
+                                         _stream(stream)))
+
+    def join(self, stream=None):
+        _ck(lib().ips_comm_join(self.h, _stream(stream)))
 
     def close(self):
         if self.h:

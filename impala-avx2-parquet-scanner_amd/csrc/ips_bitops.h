@@ -147,6 +147,32 @@ IPS_HD void planes_to_lanes(const uint32_t (&p)[W], uint32_t (&a)[32]) {
   transpose_lanes<LaneWidth<W>::R>(a);
 }
 
+// Planes -> "quads" for the wide widths (R = 32): only the three coarse stages (16, 8, 4) of the
+// 32x32 transpose -- 128 of its 256 ops.  Afterwards t[4*bh + kl] bit (4*kh + bl) = plane
+// (4*kh + kl) bit (4*bh + bl): the value at bit position b = 4*bh + bl is spread over the four
+// registers t[4*bh .. 4*bh+3] as a comb of every fourth bit,
+//     value(b) = OR over kl of (((t[4*bh + kl] >> bl) & 0x11111111) << kl)         (11 ops),
+// which the scan's index-list path evaluates for the SELECTED rows only (quads_value below): at
+// 10 % selectivity that is 4 rounds of 64 rows instead of the two fine stages for all 2048.
+template <int W>
+IPS_HD void planes_to_quads(const uint32_t (&p)[W], uint32_t (&t)[32]) {
+#pragma unroll
+  for (int i = 0; i < 32; ++i) t[i] = i < W ? p[i] : 0u;
+  transpose_stage<16, 0x0000FFFFu>(t);
+  transpose_stage<8, 0x00FF00FFu>(t);
+  transpose_stage<4, 0x0F0F0F0Fu>(t);
+}
+// the remaining fine stages: quads -> values by position (a[b] = value at bit position b)
+IPS_HD void quads_to_values(uint32_t (&t)[32]) {
+  transpose_stage<2, 0x33333333u>(t);
+  transpose_stage<1, 0x55555555u>(t);
+}
+// value at bit position 4*bh + bl from its four quad registers q0..q3 = t[4*bh .. 4*bh+3]
+IPS_HD uint32_t quads_value(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t bl) {
+  const uint32_t m = 0x11111111u;
+  return ((q0 >> bl) & m) | (((q1 >> bl) & m) << 1) | (((q2 >> bl) & m) << 2) | (((q3 >> bl) & m) << 3);
+}
+
 // Values -> planes (the encoder direction): v[j] = value of row j, p[i] = plane i bits.
 template <int W>
 IPS_HD void values_to_planes(const uint32_t (&v)[32], uint32_t (&p)[W]) {

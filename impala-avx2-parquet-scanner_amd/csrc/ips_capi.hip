@@ -79,7 +79,13 @@ int grid_for_tiles(const void* kernel, int64_t tiles) {
   int64_t want = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
   if (want < 1) want = 1;
   int64_t cap = (int64_t)cus * per_cu * grid_mult();
-  return (int)(want < cap ? want : cap);
+  if (want <= cap) return (int)want;
+  // Even shares: with 'cap' blocks and want = 1.33 * cap, a third of the blocks would make two
+  // rounds and the rest one -- the launch lasts two rounds for 1.33 rounds of work (a 2^25-row
+  // chunk of the headline column: 40 us instead of 30).  Give every block the same number of
+  // rounds k = ceil(want / cap) instead.
+  const int64_t k = (want + cap - 1) / cap;
+  return (int)((want + k - 1) / k);
 }
 
 // ---- launchers living in the other translation units ----------------------------------------

@@ -8,6 +8,8 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <vector>
+
 #include "ips_host.h"
 
 namespace {
@@ -66,6 +68,19 @@ struct ips_comm {
   NcclComm comm;
   int nranks;
   int rank;
+  // the exchange runs on the communicator's own stream; events order it against the scan stream
+  hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> events;  // grow-only pool, reused round-robin (created outside captures)
+  size_t next_event = 0;
+  hipEvent_t event() {
+    if (events.size() < 64) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      events.push_back(e);
+      return e;
+    }
+    return events[next_event++ % events.size()];
+  }
 };
 
 extern "C" {
@@ -90,14 +105,28 @@ ips_status ips_comm_init(const void* id_bytes, int nranks, int rank, ips_comm** 
   NcclComm c = nullptr;
   int rc = r->CommInitRank(&c, nranks, id, rank);
   if (rc != kNcclSuccess) return rccl_fail(r, rc, "ncclCommInitRank");
-  *comm = new ips_comm{c, nranks, rank};
+  ips_comm* out = new ips_comm();
+  out->comm = c;
+  out->nranks = nranks;
+  out->rank = rank;
+  if (hipStreamCreateWithFlags(&out->stream, hipStreamNonBlocking) != hipSuccess) {
+    r->CommDestroy(c);
+    delete out;
+    ips::set_error("ips_comm_init: cannot create the exchange stream");
+    (void)hipGetLastError();
+    return IPS_ERR_HIP;
+  }
+  *comm = out;
   return IPS_OK;
 }
 
 ips_status ips_comm_destroy(ips_comm* comm) {
   if (!comm) return IPS_OK;
   Rccl* r = rccl();
+  if (comm->stream) (void)hipStreamSynchronize(comm->stream);
   if (r) r->CommDestroy(comm->comm);
+  for (hipEvent_t e : comm->events) (void)hipEventDestroy(e);
+  if (comm->stream) (void)hipStreamDestroy(comm->stream);
   delete comm;
   return IPS_OK;
 }
@@ -112,6 +141,56 @@ ips_status ips_allgather_bitmap(ips_comm* comm, const uint64_t* d_local_words, i
   int rc = r->AllGather(d_local_words, d_all_words, (size_t)n_words, kNcclUint64, comm->comm,
                         reinterpret_cast<hipStream_t>(stream));
   if (rc != kNcclSuccess) return rccl_fail(r, rc, "ncclAllGather");
+  return IPS_OK;
+}
+
+// One step of the sharded fused scan: chunk i is scanned on 'stream'; as soon as it
+// has finished, its bitmap words are all-gathered on the communicator's stream while chunk i+1 is
+// being scanned.  All launches of the step are issued by this one call.
+ips_status ips_fle_scan_allgather(ips_comm* comm, const void* d_enc, int64_t n_rows, int bit_width,
+                                  ips_op op, const uint64_t* consts, int n_consts, int n_chunks,
+                                  uint64_t* d_local_bitmap, uint32_t* d_batch_values,
+                                  uint32_t* d_batch_counts, uint64_t* d_all_bitmap, ips_stream stream) {
+  IPS_REQUIRE(comm != nullptr, "ips_fle_scan_allgather: NULL communicator");
+  IPS_REQUIRE(n_chunks >= 1 && n_rows >= 0 && n_rows % ((int64_t)n_chunks * IPS_BATCH_ROWS) == 0,
+              "ips_fle_scan_allgather: n_rows must be n_chunks whole pieces of a multiple of %d rows", IPS_BATCH_ROWS);
+  IPS_REQUIRE(bit_width >= 1 && bit_width <= 32, "ips_fle_scan_allgather: bit width %d", bit_width);
+  IPS_REQUIRE(n_rows == 0 || (d_enc && d_local_bitmap && d_batch_values && d_batch_counts && d_all_bitmap),
+              "ips_fle_scan_allgather: NULL argument");
+  if (n_rows == 0) return IPS_OK;
+  Rccl* r = rccl();
+  if (!r) return IPS_ERR_UNSUPPORTED;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t rows_c = n_rows / n_chunks;
+  const int64_t words_c = rows_c / 64;
+  const uint8_t* enc = reinterpret_cast<const uint8_t*>(d_enc);
+  for (int i = 0; i < n_chunks; ++i) {
+    ips_status st = ips_fle_scan(enc + (size_t)i * (size_t)words_c * (size_t)bit_width * 8, rows_c, bit_width,
+                                 op, consts, n_consts, d_local_bitmap + (size_t)i * words_c,
+                                 d_batch_values + (size_t)i * rows_c,
+                                 d_batch_counts + (size_t)i * (rows_c / IPS_BATCH_ROWS), stream);
+    if (st != IPS_OK) return st;
+    hipEvent_t done = comm->event();
+    IPS_REQUIRE(done != nullptr, "ips_fle_scan_allgather: cannot create an event");
+    IPS_HIP_TRY(hipEventRecord(done, s));
+    IPS_HIP_TRY(hipStreamWaitEvent(comm->stream, done, 0));
+    // piece (i, rank) of the block-cyclic layout: chunk i of all ranks is contiguous in the column
+    int rc = r->AllGather(d_local_bitmap + (size_t)i * words_c,
+                          d_all_bitmap + (size_t)i * (size_t)comm->nranks * words_c, (size_t)words_c,
+                          kNcclUint64, comm->comm, comm->stream);
+    if (rc != kNcclSuccess) return rccl_fail(r, rc, "ncclAllGather");
+  }
+  return IPS_OK;
+}
+
+// Make 'stream' wait for everything the communicator's stream has been given so far (the gathers
+// of earlier ips_fle_scan_allgather calls): call it before reusing or reading their buffers.
+ips_status ips_comm_join(ips_comm* comm, ips_stream stream) {
+  IPS_REQUIRE(comm != nullptr, "ips_comm_join: NULL communicator");
+  hipEvent_t e = comm->event();
+  IPS_REQUIRE(e != nullptr, "ips_comm_join: cannot create an event");
+  IPS_HIP_TRY(hipEventRecord(e, comm->stream));
+  IPS_HIP_TRY(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), e, 0));
   return IPS_OK;
 }
 

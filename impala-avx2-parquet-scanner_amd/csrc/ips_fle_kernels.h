@@ -239,6 +239,10 @@ __device__ __forceinline__ void fle_scan_body(
 #endif
       constexpr int R = LaneWidth<W>::R;
       constexpr bool kPacked = IPS_INDEX_PATH && !kInTable && R < 32;  // values stay lane-packed
+#ifndef IPS_QUADS
+#define IPS_QUADS 1
+#endif
+      constexpr bool kQuads = IPS_QUADS && IPS_INDEX_PATH && !kInTable && R == 32;  // half-transposed in LDS
       const bool index_path = IPS_INDEX_PATH ? count <= (uint32_t)kIndexListMax
                                              : __builtin_amdgcn_ballot_w64(mine > kSparseLaneMax) == 0ull;
       if (IPS_INDEX_PATH && index_path) {
@@ -260,6 +264,13 @@ __device__ __forceinline__ void fle_scan_body(
             u32x4 t = {a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]};
             *reinterpret_cast<u32x4*>(lds8 + lane * kStride + 16 * i) = t;
           }
+        } else if (kQuads) {
+          // wide columns: park the half-transposed "quads" (ips_bitops.h); phase B finishes the
+          // transposition for the selected rows only
+          uint32_t t[32];
+          planes_to_quads<W>(p, t);
+          wave_lds_fence();
+          values_to_row_tile(lds32, lane, t);
         } else {
           if (!kInTable) planes_to_values<W>(p, v);
           wave_lds_fence();
@@ -286,7 +297,11 @@ __device__ __forceinline__ void fle_scan_body(
           const uint32_t e = list[i];
           const uint32_t src = e >> 5, j = e & 31u;
           uint32_t x;
-          if (!kPacked) {
+          if (kQuads) {
+            const uint32_t b = 31u - j;  // row j sits at bit position 31 - j
+            const u32x4 q = *reinterpret_cast<const u32x4*>(lds32 + src * kRowTileStrideDw + (b & ~3u));
+            x = quads_value(q.x, q.y, q.z, q.w, b & 3u);
+          } else if (!kPacked) {
             x = lds32[src * kRowTileStrideDw + j];
           } else if (R == 16) {
             x = *reinterpret_cast<const uint16_t*>(lds8 + src * kStride + 4u * ((31u - j) & 15u) + 2u * ((31u - j) >> 4));

@@ -32,20 +32,28 @@ class DictEncoderBase {
   int bit_width() const { return ips_dict_bit_width(num_entries()); }
 
   // [uint8 bit_width][FLE blocks]; returns bytes written or -1, dict-encoding.h:408-423
-  int WriteData(uint8_t* buffer, int buffer_len) {
+  int WriteData(uint8_t* buffer, int buffer_len) { return WriteData(buffer, buffer_len, buffered_indices_); }
+
+  // One data page of a chunk whose dictionary is complete: the page's insertion-order indices
+  // (the table writer keeps them per page until Flush(), hdfs-parquet-table-writer.cc:434-464,
+  // because the sorted codes exist only after WriteDict), dict-encoding.h:425-447.  The header
+  // byte is the width the codes are really packed with -- the whole dictionary's -- where the
+  // reference stores the page's own Log2(max index + 1).
+  int WriteData(uint8_t* buffer, int buffer_len, const std::vector<int>& node_indices) {
     const int bw = bit_width();
-    const int64_t need = 1 + ips_fle_encoded_bytes((int64_t)buffered_indices_.size(), bw);
+    const int64_t need = 1 + ips_fle_encoded_bytes((int64_t)node_indices.size(), bw);
     if (need > buffer_len) return -1;
     *buffer = (uint8_t)bw;
-    if (buffered_indices_.empty() || bw == 0) return 1;
+    if (node_indices.empty() || bw == 0) return 1;
     std::vector<uint8_t> blocks((size_t)need - 1);
     FleEncoder encoder(blocks.data(), (int)blocks.size(), bw);
-    for (int index : buffered_indices_)
+    for (int index : node_indices)
       if (!encoder.Put((uint64_t)to_sorted_indice_[(size_t)index])) return -1;
     const int len = encoder.Flush();
     memcpy(buffer + 1, blocks.data(), (size_t)len);  // page payload starts at an odd address
     return 1 + len;
   }
+  const std::vector<int>& buffered_indices() const { return buffered_indices_; }
 
  protected:
   DictEncoderBase() : dict_encoded_size_(0) {}

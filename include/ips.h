@@ -386,6 +386,20 @@ ips_status ips_comm_destroy(ips_comm* comm);
 ips_status ips_allgather_bitmap(ips_comm* comm, const uint64_t* d_local_words, int64_t n_words,
                                 uint64_t* d_all_words, ips_stream stream);
 
+/* One step of the sharded fused scan with the exchange overlapped INSIDE the step:
+ * the rank's rows are n_chunks pieces of n_rows / n_chunks rows (a multiple of IPS_BATCH_ROWS)
+ * in block-cyclic order -- piece i of rank r is piece i * nranks + r of the whole column -- so the
+ * all-gather of chunk i fills words [i * nranks * w, (i + 1) * nranks * w) of d_all_bitmap
+ * (w = piece words) in natural row order.  Chunk i is scanned by ips_fle_scan on 'stream' and
+ * gathered on the communicator's own stream as soon as it is done, while chunk i + 1 is scanned.
+ * Outputs d_local_bitmap / d_batch_values / d_batch_counts as ips_fle_scan over the n_rows local
+ * rows.  ips_comm_join makes a stream wait for all gathers issued so far. */
+ips_status ips_fle_scan_allgather(ips_comm* comm, const void* d_enc, int64_t n_rows, int bit_width,
+                                  ips_op op, const uint64_t* consts, int n_consts, int n_chunks,
+                                  uint64_t* d_local_bitmap, uint32_t* d_batch_values,
+                                  uint32_t* d_batch_counts, uint64_t* d_all_bitmap, ips_stream stream);
+ips_status ips_comm_join(ips_comm* comm, ips_stream stream);
+
 /* ---- synthetic data (bench / tests) --------------------------------------------------------- */
 /* d_out[i] = splitmix64(seed + i) & mask, as uint32 (SURVEY 8d generator). */
 ips_status ips_synth_splitmix_u32(uint64_t seed, int64_t n, uint32_t mask, uint32_t* d_out,

@@ -106,3 +106,33 @@ def test_stripes_scanned_by_the_hip_kernels_concatenate(capi, ips, O, n, world):
     nb = w_cnt.numel()
     assert torch.equal(capi.batches_compact(torch.cat(val_pieces), torch.cat(cnt_pieces), n),
                        capi.batches_compact(w_vals[:nb * 2048], w_cnt, n))
+
+
+def test_chunked_scan_with_overlapped_allgather_one_rank(capi, ips, O):
+    """ips_fle_scan_allgather (one C call per step: chunk scans + RCCL all-gather of every finished
+    chunk on the communicator's stream) on a one-rank communicator: the gathered bitmap, the local
+    bitmap and the batches equal a plain ips_fle_scan of the same rows and the oracle."""
+    n_chunks, bw = 8, 13
+    n = 2048 * n_chunks * 5
+    vals = ips.synth.column_u32(ips.synth.SEED_HEADLINE, n, bw)
+    c = ips.synth.lt_constant(bw)
+    enc_ref = O.fle_encode(vals, bw)
+    enc = torch.from_numpy(enc_ref.view(np.int64).copy()).cuda()
+    comm = capi.Comm(capi.comm_unique_id(), 1, 0)
+    try:
+        local, bvals, counts = capi.alloc_scan_outputs(n, enc.device)
+        full = torch.zeros(n // 64, dtype=torch.int64, device=enc.device)
+        for _ in range(3):   # repeated steps reuse the buffers behind ips_comm_join
+            comm.join()
+            comm.fle_scan_allgather(enc, n, bw, capi.OP_LT, c, n_chunks, local, bvals, counts, full)
+        comm.join()
+        torch.cuda.synchronize()
+        ref_bm, ref_vals, ref_cnt = capi.fle_scan(enc, n, bw, capi.OP_LT, c)
+        assert np.array_equal(words(full), O.fle_pred(enc_ref, n, bw, O.OP_LT, c))
+        assert torch.equal(full, ref_bm) and torch.equal(local[:n // 64], ref_bm)
+        assert torch.equal(counts[:n // 2048], ref_cnt)
+        assert torch.equal(capi.batches_compact(bvals, counts[:n // 2048], n), capi.batches_compact(ref_vals, ref_cnt, n))
+        with pytest.raises(capi.IpsError):   # rows must be whole chunks of whole batches
+            comm.fle_scan_allgather(enc, n - 2048, bw, capi.OP_LT, c, n_chunks, local, bvals, counts, full)
+    finally:
+        comm.close()
