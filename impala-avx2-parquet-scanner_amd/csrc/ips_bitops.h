@@ -47,6 +47,39 @@ IPS_HD uint32_t cmp_select(const CmpState& s, int op) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same comparisons in ONE op per plane (gfx950: v_bitop3_b32, any 3-input boolean function).
+// Walking the planes LSB -> MSB, "value < constant so far" is the borrow of value - constant:
+//     b_k = (~x_k & c_k) | (~(x_k ^ c_k) & b_{k-1})        b_{-1} = 0 -> x < c,  b_{-1} = ~0 -> x <= c
+// so LT / LE are the final borrow with the matching start value and GT / GE its complement; EQ is
+// its own one-op chain.  (The reference runs MSB -> LSB with two masks, fle-encoding.h:8039-8042;
+// the result is the same predicate.)  Truth tables: operands (src0, src1, src2) <-> 0xF0, 0xCC, 0xAA.
+// ---------------------------------------------------------------------------------------------
+IPS_HD uint32_t borrow_step(uint32_t b, uint32_t x, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(b, x, c, 0xB2);  // (~x & c) | (~(x ^ c) & b)
+#else
+  return (~x & c) | (~(x ^ c) & b);
+#endif
+}
+IPS_HD uint32_t eq_step(uint32_t eq, uint32_t x, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(eq, x, c, 0x90);  // eq & ~(x ^ c)
+#else
+  return eq & ~(x ^ c);
+#endif
+}
+IPS_HD uint32_t ne_step(uint32_t ne, uint32_t x, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(ne, x, c, 0xF6);  // ne | (x ^ c)
+#else
+  return ne | (x ^ c);
+#endif
+}
+// start value of the borrow chain for LT(1) / LE(2) / GT(3) / GE(4), and the final selection
+IPS_HD uint32_t borrow_init(int op) { return (op == 2 || op == 3) ? ~0u : 0u; }
+IPS_HD uint32_t borrow_select(uint32_t b, int op) { return op >= 3 ? ~b : b; }
+
 IPS_HD uint32_t bitrev32(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_bitreverse32(v);
@@ -168,9 +201,19 @@ IPS_HD void quads_to_values(uint32_t (&t)[32]) {
   transpose_stage<1, 0x55555555u>(t);
 }
 // value at bit position 4*bh + bl from its four quad registers q0..q3 = t[4*bh .. 4*bh+3]
-IPS_HD uint32_t quads_value(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t bl) {
-  const uint32_t m = 0x11111111u;
+IPS_HD uint32_t quads_value(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t bl,
+                            uint32_t m = 0x11111111u) {
   return ((q0 >> bl) & m) | (((q1 >> bl) & m) << 1) | (((q2 >> bl) & m) << 2) | (((q3 >> bl) & m) << 3);
+}
+// The same for 9..16-bit columns (R = 16: two values side by side per register): only the stages
+// 8 and 4 of transpose_lanes<16> (48 of 112 ops); the value at bit position 16*q + 4*bh + bl is
+// quads_value(t[4*bh .. 4*bh+3], 16*q + bl, 0x1111).
+template <int W>
+IPS_HD void planes_to_lane_quads16(const uint32_t (&p)[W], uint32_t (&t)[32]) {
+#pragma unroll
+  for (int i = 0; i < 32; ++i) t[i] = i < W ? p[i] : 0u;
+  transpose_stage<8, 0x00FF00FFu>(t);
+  transpose_stage<4, 0x0F0F0F0Fu>(t);
 }
 
 // Values -> planes (the encoder direction): v[j] = value of row j, p[i] = plane i bits.

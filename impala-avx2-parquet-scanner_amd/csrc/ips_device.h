@@ -187,51 +187,63 @@ __device__ __forceinline__ int plane_base_dw(int w, int lane) {
 }
 
 // ---- predicate on the encoded planes, streaming from LDS (any w, nothing kept in VGPRs) -----
+// One v_bitop3_b32 per plane (ips_bitops.h: borrow_step / eq_step), planes taken LSB -> MSB.
 __device__ __forceinline__ uint32_t pred_single_from_lds(const uint32_t* lds32, int w, int lane,
                                                          int op, uint32_t c) {
   const uint32_t* p = lds32 + plane_base_dw(w, lane);
-  CmpState s{0u, ~0u};
-  int k = w - 1;
-  for (; k >= 7; k -= 8) {  // 8 independent LDS reads in flight per round trip
+  const bool is_eq = op == 0;  // wave-uniform
+  uint32_t acc = is_eq ? ~0u : borrow_init(op);
+  int k = 0;
+  for (; k + 8 <= w; k += 8) {  // 8 independent LDS reads in flight per round trip
     uint32_t x[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = p[2 * (k - e)];
+    for (int e = 0; e < 8; ++e) x[e] = p[2 * (k + e)];
+    if (is_eq) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) cmp_step(s, x[e], bit_mask(c, k - e));
+      for (int e = 0; e < 8; ++e) acc = eq_step(acc, x[e], bit_mask(c, k + e));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc = borrow_step(acc, x[e], bit_mask(c, k + e));
+    }
   }
-  if (k >= 3) {  // then 4
-    uint32_t x3 = p[2 * k], x2 = p[2 * k - 2], x1 = p[2 * k - 4], x0 = p[2 * k - 6];
-    cmp_step(s, x3, bit_mask(c, k));
-    cmp_step(s, x2, bit_mask(c, k - 1));
-    cmp_step(s, x1, bit_mask(c, k - 2));
-    cmp_step(s, x0, bit_mask(c, k - 3));
-    k -= 4;
+  for (; k < w; ++k) {
+    const uint32_t x = p[2 * k];
+    acc = is_eq ? eq_step(acc, x, bit_mask(c, k)) : borrow_step(acc, x, bit_mask(c, k));
   }
-  for (; k >= 0; --k) cmp_step(s, p[2 * k], bit_mask(c, k));  // 0..3 planes left
-  return cmp_select(s, op);
+  return is_eq ? acc : borrow_select(acc, op);
 }
 
-// Two comparisons against the same column in one pass over its planes (a BETWEEN).
+// Two comparisons against the same column in one pass over its planes (a BETWEEN): two chains,
+// two ops per plane (an EQ member takes the generic per-plane select).
 __device__ __forceinline__ void pred_pair_from_lds(const uint32_t* lds32, int w, int lane, int op1,
                                                    uint32_t c1, int op2, uint32_t c2,
                                                    uint32_t* r1, uint32_t* r2) {
   const uint32_t* p = lds32 + plane_base_dw(w, lane);
-  CmpState s1{0u, ~0u}, s2{0u, ~0u};
-  int k = w - 1;
-  for (; k >= 3; k -= 4) {
-    uint32_t x3 = p[2 * k], x2 = p[2 * k - 2], x1 = p[2 * k - 4], x0 = p[2 * k - 6];
-    cmp_step(s1, x3, bit_mask(c1, k));     cmp_step(s2, x3, bit_mask(c2, k));
-    cmp_step(s1, x2, bit_mask(c1, k - 1)); cmp_step(s2, x2, bit_mask(c2, k - 1));
-    cmp_step(s1, x1, bit_mask(c1, k - 2)); cmp_step(s2, x1, bit_mask(c2, k - 2));
-    cmp_step(s1, x0, bit_mask(c1, k - 3)); cmp_step(s2, x0, bit_mask(c2, k - 3));
+  const bool eq1 = op1 == 0, eq2 = op2 == 0;
+  uint32_t a1 = eq1 ? ~0u : borrow_init(op1), a2 = eq2 ? ~0u : borrow_init(op2);
+  if (!eq1 && !eq2) {
+    int k = 0;
+    for (; k + 4 <= w; k += 4) {
+      const uint32_t x0 = p[2 * k], x1 = p[2 * k + 2], x2 = p[2 * k + 4], x3 = p[2 * k + 6];
+      a1 = borrow_step(a1, x0, bit_mask(c1, k));     a2 = borrow_step(a2, x0, bit_mask(c2, k));
+      a1 = borrow_step(a1, x1, bit_mask(c1, k + 1)); a2 = borrow_step(a2, x1, bit_mask(c2, k + 1));
+      a1 = borrow_step(a1, x2, bit_mask(c1, k + 2)); a2 = borrow_step(a2, x2, bit_mask(c2, k + 2));
+      a1 = borrow_step(a1, x3, bit_mask(c1, k + 3)); a2 = borrow_step(a2, x3, bit_mask(c2, k + 3));
+    }
+    for (; k < w; ++k) {
+      const uint32_t x = p[2 * k];
+      a1 = borrow_step(a1, x, bit_mask(c1, k));
+      a2 = borrow_step(a2, x, bit_mask(c2, k));
+    }
+  } else {
+    for (int k = 0; k < w; ++k) {
+      const uint32_t x = p[2 * k];
+      a1 = eq1 ? eq_step(a1, x, bit_mask(c1, k)) : borrow_step(a1, x, bit_mask(c1, k));
+      a2 = eq2 ? eq_step(a2, x, bit_mask(c2, k)) : borrow_step(a2, x, bit_mask(c2, k));
+    }
   }
-  for (; k >= 0; --k) {
-    uint32_t x = p[2 * k];
-    cmp_step(s1, x, bit_mask(c1, k));
-    cmp_step(s2, x, bit_mask(c2, k));
-  }
-  *r1 = cmp_select(s1, op1);
-  *r2 = cmp_select(s2, op2);
+  *r1 = eq1 ? a1 : borrow_select(a1, op1);
+  *r2 = eq2 ? a2 : borrow_select(a2, op2);
 }
 
 // IN: the planes are re-read from LDS once per constant, never from HBM (the reference makes K
@@ -244,17 +256,17 @@ __device__ __forceinline__ uint32_t pred_in_from_lds(const uint32_t* lds32, int 
 #pragma unroll 1
   for (int j = 0; j < n_consts; ++j) {
     const uint32_t c = (uint32_t)consts[j];
-    uint32_t eq = ~0u;
+    uint32_t ne = 0u;
     int k = w - 1;
     for (; k >= 3; k -= 4) {
       uint32_t x3 = p[2 * k], x2 = p[2 * k - 2], x1 = p[2 * k - 4], x0 = p[2 * k - 6];
-      eq &= ~(x3 ^ bit_mask(c, k));
-      eq &= ~(x2 ^ bit_mask(c, k - 1));
-      eq &= ~(x1 ^ bit_mask(c, k - 2));
-      eq &= ~(x0 ^ bit_mask(c, k - 3));
+      ne = ne_step(ne, x3, bit_mask(c, k));
+      ne = ne_step(ne, x2, bit_mask(c, k - 1));
+      ne = ne_step(ne, x1, bit_mask(c, k - 2));
+      ne = ne_step(ne, x0, bit_mask(c, k - 3));
     }
-    for (; k >= 0; --k) eq &= ~(p[2 * k] ^ bit_mask(c, k));
-    any |= eq;
+    for (; k >= 0; --k) ne = ne_step(ne, p[2 * k], bit_mask(c, k));
+    any |= ~ne;
   }
   return any;
 }
@@ -276,42 +288,46 @@ __device__ __forceinline__ uint32_t pred_from_lds(const uint32_t* lds32, int w, 
 template <int W>
 __device__ __forceinline__ uint32_t pred_from_regs(const uint32_t (&p)[W], const PredArgs& a) {
   const uint32_t c = a.consts[0];
-  CmpState s{0u, ~0u};
+  if (a.op == 0) {  // wave-uniform
+    uint32_t eq = ~0u;
 #pragma unroll
-  for (int k = W - 1; k >= 0; --k) cmp_step(s, p[k], bit_mask(c, k));
-  return cmp_select(s, a.op);
+    for (int k = 0; k < W; ++k) eq = eq_step(eq, p[k], bit_mask(c, k));
+    return eq;
+  }
+  uint32_t b = borrow_init(a.op);
+#pragma unroll
+  for (int k = 0; k < W; ++k) b = borrow_step(b, p[k], bit_mask(c, k));
+  return borrow_select(b, a.op);
 }
 
 // IN on planes in registers (W <= 16: every dictionary code width): one bit-select op per plane
 // and constant, four constants per round so the scalar loads of the list are batched.
+// not-equal mask of the half-block against one constant: ne | (plane ^ constant bit), one
+// v_bitop3_b32 per plane
+template <int W>
+__device__ __forceinline__ uint32_t ne_const(const uint32_t (&p)[W], uint32_t c) {
+  uint32_t ne = 0u;
+#pragma unroll
+  for (int k = 0; k < W; ++k) ne = ne_step(ne, p[k], bit_mask(c, k));
+  return ne;
+}
+
 template <int W, typename ConstsPtrT>
 __device__ __forceinline__ uint32_t pred_in_from_regs(const uint32_t (&p)[W], ConstsPtrT consts,
                                                       int n_consts) {
-  uint32_t any = 0u;
+  uint32_t none = ~0u;  // rows equal to none of the constants so far
   int j = 0;
 #pragma unroll 1
   for (; j + 4 <= n_consts; j += 4) {
     const uint32_t c0 = (uint32_t)consts[j], c1 = (uint32_t)consts[j + 1];
     const uint32_t c2 = (uint32_t)consts[j + 2], c3 = (uint32_t)consts[j + 3];
-    uint32_t e0 = ~0u, e1 = ~0u, e2 = ~0u, e3 = ~0u;
-#pragma unroll
-    for (int k = W - 1; k >= 0; --k) {
-      e0 &= ~(p[k] ^ bit_mask(c0, k));
-      e1 &= ~(p[k] ^ bit_mask(c1, k));
-      e2 &= ~(p[k] ^ bit_mask(c2, k));
-      e3 &= ~(p[k] ^ bit_mask(c3, k));
-    }
-    any |= (e0 | e1) | (e2 | e3);
+    const uint32_t n0 = ne_const<W>(p, c0), n1 = ne_const<W>(p, c1);
+    const uint32_t n2 = ne_const<W>(p, c2), n3 = ne_const<W>(p, c3);
+    none &= (n0 & n1) & (n2 & n3);
   }
 #pragma unroll 1
-  for (; j < n_consts; ++j) {
-    const uint32_t c = (uint32_t)consts[j];
-    uint32_t eq = ~0u;
-#pragma unroll
-    for (int k = W - 1; k >= 0; --k) eq &= ~(p[k] ^ bit_mask(c, k));
-    any |= eq;
-  }
-  return any;
+  for (; j < n_consts; ++j) none &= ne_const<W>(p, (uint32_t)consts[j]);
+  return ~none;
 }
 
 // Bitmap dword of this lane: bit j <-> row 32q+j of the block; rows >= n_rows are cleared.

@@ -43,7 +43,9 @@ constexpr int kDecodeDictLdsBytes = 32768;
 // Long IN lists on narrow columns (every dictionary code width): membership becomes a 2^W-bit set
 // in LDS, built once per workgroup, and each decoded value costs one LDS read -- independent of
 // the list length -- instead of W bit-select steps per constant.
-constexpr int kInTableMinConsts = 10;  // below this the K*W plane steps are cheaper (host-side choice)
+// Below in_table_min_consts(W) constants the K * W plane steps on registers are cheaper than
+// decoding every row and looking it up (about 48..112 ops of transposition + 6 per row).
+constexpr int in_table_min_consts(int w) { return w <= 8 ? 32 : w <= 12 ? 26 : 20; }
 template <int W>
 struct InTable {
   static constexpr bool kUse = W <= 16;
@@ -243,6 +245,10 @@ __device__ __forceinline__ void fle_scan_body(
 #define IPS_QUADS 1
 #endif
       constexpr bool kQuads = IPS_QUADS && IPS_INDEX_PATH && !kInTable && R == 32;  // half-transposed in LDS
+#ifndef IPS_QUADS16
+#define IPS_QUADS16 1  // w=16 / 12 / 10 LT @10 %: 134 -> 117 / 127 -> 111 / 114 -> 100 us
+#endif
+      constexpr bool kQuads16 = IPS_QUADS16 && kPacked && R == 16;
       const bool index_path = IPS_INDEX_PATH ? count <= (uint32_t)kIndexListMax
                                              : __builtin_amdgcn_ballot_w64(mine > kSparseLaneMax) == 0ull;
       if (IPS_INDEX_PATH && index_path) {
@@ -257,7 +263,7 @@ __device__ __forceinline__ void fle_scan_body(
         constexpr int kStride = packed_lane_stride(kPacked ? R : 32);
         if (kPacked) {
           uint32_t a[32];
-          planes_to_lanes<W>(p, a);
+          if (kQuads16) planes_to_lane_quads16<W>(p, a); else planes_to_lanes<W>(p, a);
           wave_lds_fence();  // all plane reads precede the overwrite of the same LDS region
 #pragma unroll
           for (int i = 0; i < R / 4; ++i) {
@@ -303,6 +309,10 @@ __device__ __forceinline__ void fle_scan_body(
             x = quads_value(q.x, q.y, q.z, q.w, b & 3u);
           } else if (!kPacked) {
             x = lds32[src * kRowTileStrideDw + j];
+          } else if (kQuads16) {
+            const uint32_t b = 31u - j;
+            const u32x4 q = *reinterpret_cast<const u32x4*>(lds8 + src * kStride + 4u * (b & 12u));
+            x = quads_value(q.x, q.y, q.z, q.w, (b & 16u) | (b & 3u), 0x1111u);
           } else if (R == 16) {
             x = *reinterpret_cast<const uint16_t*>(lds8 + src * kStride + 4u * ((31u - j) & 15u) + 2u * ((31u - j) >> 4));
           } else {
@@ -537,16 +547,28 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_ear
       dst[0] = r[i].x; dst[1] = r[i].y; dst[2] = r[i].z; dst[3] = r[i].w;
     }
   };
-  auto planes_step = [&](int half, CmpState& st, CmpState& st2) {
+  // One half (16 planes, taken LSB -> MSB) of the comparison against constant cc: the borrow
+  // chain started from b0 and the equality chain (ips_bitops.h), one v_bitop3_b32 each per plane.
+  // The halves compose as  borrow(31..0) = borrow_hi(from 0) | (eq_hi & borrow_lo(from init)).
+  struct Half { uint32_t b, eq; };
+  auto planes_step = [&](int half, uint32_t cc, uint32_t b0) -> Half {
     const uint32_t* p = lds32 + plane_base_dw(W, lane);
     uint32_t x[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = p[2 * (half * 16 + 15 - e)];
+    for (int e = 0; e < 16; ++e) x[e] = p[2 * (half * 16 + e)];
+    Half h{b0, ~0u};
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      cmp_step(st, x[e], bit_mask(c, half * 16 + 15 - e));
-      if (PAIR) cmp_step(st2, x[e], bit_mask(c2, half * 16 + 15 - e));
+      h.b = borrow_step(h.b, x[e], bit_mask(cc, half * 16 + e));
+      h.eq = eq_step(h.eq, x[e], bit_mask(cc, half * 16 + e));
     }
+    return h;
+  };
+  // result of op from the high half and (when it was needed) the low half
+  auto finish = [&](int op, const Half& hi, bool with_lo, const Half& lo) -> uint32_t {
+    if (op == 0) return with_lo ? (hi.eq & lo.eq) : 0u;  // without the low half no row was still equal
+    const uint32_t b = with_lo ? (hi.b | (hi.eq & lo.b)) : hi.b;
+    return borrow_select(b, op);
   };
 
   int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -559,12 +581,13 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_ear
     if (have_low) stage_half(0, rl);
     const int64_t next = tile + stride;
     wave_lds_fence();
-    CmpState st{0u, ~0u}, st2{0u, ~0u};
-    planes_step(1, st, st2);
+    const Half hi = planes_step(1, c, 0u);
+    Half hi2{0u, 0u}, lo{0u, 0u}, lo2{0u, 0u};
+    if (PAIR) hi2 = planes_step(1, c2, 0u);
     // rows beyond n_rows are padding: never let them ask for the low planes
     const int64_t valid = n_rows - (tile * kRowsPerTile + (int64_t)lane * 32);
     const uint32_t live = valid >= 32 ? ~0u : valid <= 0 ? 0u : ~((1u << (32 - valid)) - 1u);  // MSB-first rows
-    const uint32_t open_rows = (PAIR ? (st.eq | st2.eq) : st.eq) & live;
+    const uint32_t open_rows = (PAIR ? (hi.eq | hi2.eq) : hi.eq) & live;
     const bool undecided = __builtin_amdgcn_ballot_w64(open_rows != 0u) != 0ull;
     if (next < tiles) {  // prefetch: the high half always, the low half while the column needs it
       load_half(next, 1, rh);
@@ -577,12 +600,13 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_ear
         stage_half(0, now);
         wave_lds_fence();
       }
-      planes_step(0, st, st2);
+      lo = planes_step(0, c, borrow_init(args.op));
+      if (PAIR) lo2 = planes_step(0, c2, borrow_init(args.op2));
     }
     with_low = undecided;
-    uint32_t sel = cmp_select(st, args.op);
+    uint32_t sel = finish(args.op, hi, undecided, lo);
     if (PAIR) {
-      const uint32_t sel2 = cmp_select(st2, args.op2);
+      const uint32_t sel2 = finish(args.op2, hi2, undecided, lo2);
       sel = args.join == 1 ? (sel & sel2) : (sel | sel2);
     }
     uint32_t bm = finish_bitmap_dword(sel, tile, lane, n_rows);

@@ -41,7 +41,7 @@ static ips_status launch_w(int mode, int gather, const uint64_t* enc, int64_t n_
     if (mode == kScanPredicate) return launch_one<W, kScanPredicate, 0>(IPS_ARGS);
     if (mode == kScanInList) {
       if constexpr (W <= 16) {
-        if (args.n_consts >= kInTableMinConsts) return launch_one<W, kScanInTable, 0>(IPS_ARGS);
+        if (args.n_consts >= in_table_min_consts(W)) return launch_one<W, kScanInTable, 0>(IPS_ARGS);
       }
       return launch_one<W, kScanInList, 0>(IPS_ARGS);
     }
@@ -52,7 +52,7 @@ static ips_status launch_w(int mode, int gather, const uint64_t* enc, int64_t n_
       if (gather == 4) return launch_one<W, kScanPredicate, 4>(IPS_ARGS);
       if (gather == 8) return launch_one<W, kScanPredicate, 8>(IPS_ARGS);
     }
-    if (mode == kScanInList && args.n_consts >= kInTableMinConsts) {
+    if (mode == kScanInList && args.n_consts >= in_table_min_consts(W)) {
       if (gather == 4) return launch_one<W, kScanInTable, 4>(IPS_ARGS);
       if (gather == 8) return launch_one<W, kScanInTable, 8>(IPS_ARGS);
     }
@@ -146,7 +146,7 @@ static ips_status launch_pred_w(const uint64_t* enc, int64_t n_rows, const PredA
   if (args.join != 0) return launch_pred_wk<W, kPredPair>(enc, n_rows, args, bitmap32, s);
   if (args.op == 5) {
     if constexpr (W <= 16) {
-      if (args.n_consts >= kInTableMinConsts) return launch_pred_wk<W, kPredInTable>(enc, n_rows, args, bitmap32, s);
+      if (args.n_consts >= in_table_min_consts(W)) return launch_pred_wk<W, kPredInTable>(enc, n_rows, args, bitmap32, s);
     }
     return launch_pred_wk<W, kPredInList>(enc, n_rows, args, bitmap32, s);
   }

@@ -334,6 +334,8 @@ ips_status launch_plain_pred(int type, const void* page, int64_t n_rows, int op,
 // bits four at a time -- four independent slot loads in flight -- and stores them in row order.
 // Same batch layout as ips_fle_select.
 // =============================================================================================
+constexpr uint32_t kPlainSelectStreamMin = 64;  // selected rows per 2048-row batch (3 %)
+
 template <typename S>
 __global__ __launch_bounds__(kThreads) void plain_select_kernel(
     const S* __restrict__ page, int64_t n_rows, const uint32_t* __restrict__ bitmap32,
@@ -355,6 +357,58 @@ __global__ __launch_bounds__(kThreads) void plain_select_kernel(
     uint32_t P = incl - mine;
     const S* src = page + row0;
     S* dst = batch_values + batch * kRowsPerTile;
+    // Above a few per cent selectivity nearly every 128-byte line of the batch holds a selected
+    // row (10 %: 81 % of the lines of an 8-byte column), and fetching them through scattered
+    // 8-byte loads costs far more than their bytes: stream the whole batch with coalesced 16-byte
+    // loads instead and rank the selected slots with the ballots of their bitmap bits (the
+    // materialisation half of plain_scan_kernel).  Wave-uniform choice per batch.
+    constexpr int RPL = 16 / (int)sizeof(S);
+    constexpr int U = kRowsPerTile / (64 * RPL);
+    constexpr int UH = 8;
+    const int64_t batch_row0 = batch * kRowsPerTile;
+    if (count >= kPlainSelectStreamMin && batch_row0 + kRowsPerTile <= n_rows) {
+      uint32_t base = 0;
+#pragma unroll 1
+      for (int h = 0; h < U / UH; ++h) {
+        S raw[UH][RPL];
+        uint32_t bits[UH];
+#pragma unroll
+        for (int u = 0; u < UH; ++u) {
+          const int r = (h * UH + u) * 64 * RPL + lane * RPL;  // first row of this lane's load
+          u32x4 t = stream_load(reinterpret_cast<const u32x4*>(page + batch_row0 + r));
+          __builtin_memcpy(raw[u], &t, 16);
+          bits[u] = bitmap32[batch * 64 + (r >> 5)] >> (r & 31);
+        }
+#pragma unroll
+        for (int u = 0; u < UH; ++u) {
+          uint64_t mm[RPL];
+          bool sel_e[RPL];
+#pragma unroll
+          for (int e = 0; e < RPL; ++e) {
+            sel_e[e] = ((bits[u] >> e) & 1u) != 0u;
+            mm[e] = __builtin_amdgcn_ballot_w64(sel_e[e]);
+          }
+          uint64_t any = mm[0];
+#pragma unroll
+          for (int e = 1; e < RPL; ++e) any |= mm[e];
+          if (any != 0ull) {  // wave-uniform
+            uint32_t Q = base;
+            uint32_t total = 0;
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) {
+              Q += __builtin_amdgcn_mbcnt_hi((uint32_t)(mm[e] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm[e], 0u));
+              total += (uint32_t)__builtin_popcountll(mm[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < RPL; ++e)
+              if (sel_e[e]) dst[Q++] = raw[u][e];
+            base += total;
+          }
+        }
+      }
+      if (lane == 0) batch_counts[batch] = count;
+      continue;
+    }
     while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
       S x[4];
       bool ok[4];

@@ -46,6 +46,61 @@ static void test_width() {
           CHECK((bool)((bm >> j) & 1u) == e);
         }
       }
+      // the one-op-per-plane forms the kernels use (LSB -> MSB borrow / equality chains), also
+      // composed from two halves as the w=32 early-pruning kernel does
+      for (int op = 0; op < 5; ++op) {
+        uint32_t acc = op == 0 ? ~0u : ips::borrow_init(op);
+        for (int k = 0; k < W; ++k) {
+          const uint32_t cm = ((c >> k) & 1u) ? ~0u : 0u;
+          acc = op == 0 ? ips::eq_step(acc, p[k], cm) : ips::borrow_step(acc, p[k], cm);
+        }
+        const uint32_t sel = op == 0 ? acc : ips::borrow_select(acc, op);
+        CHECK(sel == ips::cmp_select(s, op));
+        const int split = W / 2;
+        uint32_t blo = ips::borrow_init(op), eqlo = ~0u, bhi = 0u, eqhi = ~0u;
+        for (int k = 0; k < split; ++k) {
+          const uint32_t cm = ((c >> k) & 1u) ? ~0u : 0u;
+          blo = ips::borrow_step(blo, p[k], cm); eqlo = ips::eq_step(eqlo, p[k], cm);
+        }
+        for (int k = split; k < W; ++k) {
+          const uint32_t cm = ((c >> k) & 1u) ? ~0u : 0u;
+          bhi = ips::borrow_step(bhi, p[k], cm); eqhi = ips::eq_step(eqhi, p[k], cm);
+        }
+        const uint32_t composed = op == 0 ? (eqhi & eqlo) : ips::borrow_select(bhi | (eqhi & blo), op);
+        CHECK(composed == ips::cmp_select(s, op));
+      }
+      uint32_t ne = 0u;
+      for (int k = 0; k < W; ++k) ne = ips::ne_step(ne, p[k], ((c >> k) & 1u) ? ~0u : 0u);
+      CHECK(~ne == s.eq);
+    }
+    // half-transposed forms of the scan's index-list path
+    if (W > 16) {
+      uint32_t t[32];
+      ips::planes_to_quads<W>(p, t);
+      for (int j = 0; j < 32; ++j) {
+        const uint32_t b = 31u - (uint32_t)j;
+        CHECK(ips::quads_value(t[b & ~3u], t[(b & ~3u) + 1], t[(b & ~3u) + 2], t[(b & ~3u) + 3], b & 3u) == v[j]);
+      }
+      ips::quads_to_values(t);
+      for (int j = 0; j < 32; ++j) CHECK(t[31 - j] == v[j]);
+    } else if (W > 8) {
+      uint32_t t[32];
+      ips::planes_to_lane_quads16<W>(p, t);
+      for (int j = 0; j < 32; ++j) {
+        const uint32_t b = 31u - (uint32_t)j;
+        const uint32_t base = b & 12u;
+        CHECK(ips::quads_value(t[base], t[base + 1], t[base + 2], t[base + 3], (b & 16u) | (b & 3u), 0x1111u) == v[j]);
+      }
+    }
+    {
+      uint32_t a[32];
+      ips::planes_to_lanes<W>(p, a);
+      constexpr int R = ips::LaneWidth<W>::R;
+      for (int j = 0; j < 32; ++j) {
+        const int pos = 31 - j;
+        if (R == 32) CHECK(a[pos] == v[j]);
+        else CHECK(((a[pos % R] >> (R * (pos / R))) & ((1u << R) - 1u)) == v[j]);
+      }
     }
   }
 }
