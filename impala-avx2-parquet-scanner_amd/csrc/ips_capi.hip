@@ -889,7 +889,10 @@ ips_status ips_bitmap_count(const uint64_t* d_a, int64_t n_rows, int64_t* d_coun
   IPS_REQUIRE(n_rows >= 0 && d_count && (n_rows == 0 || d_a), "ips_bitmap_count: bad argument");
   return launch_bitmap_count(d_a, n_rows, d_count, S(stream));
 }
-size_t ips_expand_workspace_bytes(int64_t n_rows) { return scan_workspace_bytes((n_rows + 63) / 64); }
+size_t ips_expand_workspace_bytes(int64_t n_rows) {  // shared by ips_bitmap_expand and ips_bitmap_compress
+  const size_t a = scan_workspace_bytes((n_rows + 63) / 64), b = rank_workspace_bytes(n_rows < 0 ? 0 : n_rows);
+  return a > b ? a : b;
+}
 ips_status ips_bitmap_compress(const uint64_t* d_mask, const uint64_t* d_src, int64_t n_rows,
                                uint64_t* d_out, int64_t* d_n_out, void* d_workspace,
                                ips_stream stream) {

@@ -540,6 +540,36 @@ def test_entry_points_capture_into_a_graph(capi, O):
                           ((a2 < 500) & (b >= 10)) | ((a2 >= 3500) & (b < 5)))
 
 
+def test_nan_has_no_dictionary_order(capi, O):
+    """FLOAT / DOUBLE dictionaries are ordered by operator< (dict-encoding.h:370-372, quirk Q16):
+    a NaN gives std::sort / lower_bound no strict weak order.  The build refuses such dictionaries
+    (the writer falls back to PLAIN, as for more than 40000 entries) and a NaN literal selects no row."""
+    for t, npt, tt in ((O.T_FLOAT, np.float32, torch.float32), (O.T_DOUBLE, np.float64, torch.float64)):
+        vals = np.array([1.5, np.nan, -2.0, 1.5, 7.25, np.nan, 0.0] * 50, dtype=npt)
+        with pytest.raises(capi.IpsError) as ei:
+            capi.dict_encode(torch.from_numpy(vals).cuda(), t)
+        assert ei.value.status == 2          # IPS_ERR_UNSUPPORTED: use PLAIN
+        page = np.sort(np.array([-2.0, 0.0, 1.5, 7.25], dtype=npt))
+        with pytest.raises(capi.IpsError):   # a dictionary page holding a NaN is not ascending
+            capi.Dict(np.append(page, npt(np.nan)).view(np.uint8), t)
+        # the same column without the NaNs encodes; NaN literals translate to "no row"
+        clean = vals[~np.isnan(vals)]
+        pg, bw, enc = capi.dict_encode(torch.from_numpy(clean).cuda(), t)
+        assert np.array_equal(pg.view(npt), page) and bw == 2
+        dd = capi.Dict(pg, t)
+        for op in (O.OP_EQ, O.OP_LT, O.OP_LE, O.OP_GT, O.OP_GE):
+            assert dd.translate(op, npt(np.nan))[0] == capi.XL_ALL_FALSE
+            assert not words(dd.pred(enc, len(clean), bw, op, npt(np.nan))).any()
+        kind, fle_op, codes = dd.translate(O.OP_IN, np.array([np.nan, 1.5, np.nan], dtype=npt))
+        assert kind == capi.XL_FLE and codes == [2]
+        dd.close()
+    # the plain-select streaming path keeps NaN payloads bit-exact (they are just slots)
+    page64 = torch.from_numpy(np.tile(np.array([np.nan, 1.0, -0.0, np.inf]), 4096)).cuda()
+    bm = torch.full((page64.numel() // 64,), -1, dtype=torch.int64, device="cuda")
+    bv, cnt = capi.plain_select(page64.view(torch.int64), page64.numel(), O.T_DOUBLE, bm)
+    assert torch.equal(capi.batches_compact(bv, cnt, page64.numel()), page64.view(torch.int64))
+
+
 @pytest.mark.parametrize("type_name", TYPES)
 def test_plain_select(capi, O, type_name):
     """Late materialisation on PLAIN pages: the slots of the rows a bitmap selects, per batch, in
