@@ -44,9 +44,9 @@ for bw in (32, 16, 8):
     outs = capi.alloc_scan_outputs(n, dev)
     ow = 1 if bw <= 8 else 2 if bw <= 16 else 4
     dec = torch.empty(n, dtype={1: torch.uint8, 2: torch.int16, 4: torch.int32}[ow], device=dev)
-    run(f"fle_pred w={bw} LT", f"fle_pred{'32_early' if bw == 32 else '_w'}_kernel<{bw},", W * 8 * (bw + 1),
+    run(f"fle_pred w={bw} LT", f"fle_pred32_early_kernel<32, false>" if bw == 32 else f"fle_pred_w_kernel<{bw}, 0>", W * 8 * (bw + 1),
         lambda: capi.fle_pred(enc, n, bw, capi.OP_LT, c, bitmap=outs[0]))
-    run(f"fle_pred w={bw} BETWEEN", f"kernel<{bw},", W * 8 * (bw + 1),
+    run(f"fle_pred w={bw} BETWEEN", f"fle_pred32_early_kernel<32, true>" if bw == 32 else f"fle_pred_w_kernel<{bw}, 1>", W * 8 * (bw + 1),
         lambda: capi.eval_program([capi.leaf(0, capi.OP_GE, c // 2), capi.leaf(0, capi.OP_LT, c), capi.and_node()],
                                   [capi.fle_column(enc, bw)], n, bitmap=outs[0]))
     capi.fle_scan(enc, n, bw, capi.OP_LT, c, outputs=outs)
@@ -104,7 +104,7 @@ cnt = torch.zeros(2, dtype=torch.int64, device=dev)
 dense = torch.empty(n, dtype=torch.int32, device=dev)
 run("bitmap_and", "bitmap_binop_kernel", 3 * W * 8, lambda: lib.ips_bitmap_and(P(acc), P(bm50), N, S))
 run("bitmap_count", "bitmap_count_kernel", W * 8, lambda: lib.ips_bitmap_count(P(bm10), N, P(cnt), S))
-run("bitmap_expand (root 50%)", "expand_kernel", 3 * W * 8, lambda: lib.ips_bitmap_expand(P(bm50), P(bm10), N, P(out_bm), P(ws), S))
+run("bitmap_expand (root 50%)", "expand_kernel<0>", 3 * W * 8, lambda: lib.ips_bitmap_expand(P(bm50), P(bm10), N, P(out_bm), P(ws), S))
 run("bitmap_compress (mask 50%)", "bitmap_compress_kernel", 3 * W * 8,
     lambda: lib.ips_bitmap_compress(P(bm50), P(bm10), N, P(out_bm), P(cnt), P(ws), S))
 run("batches_compact @10%", "batches_compact_kernel", 8 * nsel + counts.numel() * 4,
@@ -146,7 +146,7 @@ del is_set
 venc = capi.fle_encode(capi.synth_u32(0x5EED0D2, k, 12), 12)
 n_data = ((k + 63) // 64) * 64
 wsn = capi.nullable_workspace(n, dev)
-run("nullable leaf w=12, 10% NULL (pred + expand)", "expand_kernel", W * 16 + n_data // 64 * 96,
+run("nullable leaf w=12, 10% NULL (pred + expand)", "expand_kernel<1>", W * 16 + n_data // 64 * 96,
     lambda: capi.fle_pred_nullable(defs, 1, 1, n, venc, n_data, 12, capi.OP_LT, 409, bitmap=bm, workspace=wsn))
 del defs, venc, wsn
 
@@ -158,4 +158,4 @@ encs = [capi.fle_encode(codes[c], q6.COLUMNS[c][3]) for c in range(3)]
 del codes
 nodes, cols = q6.program(capi, encs)
 bmq = torch.empty((nq + 63) // 64, dtype=torch.int64, device=dev)
-run("Q6 conjunction, 3 columns (3 launches)", "fle_pred_w_kernel", q6.algorithmic_bytes(nq), lambda: capi.eval_program(nodes, cols, nq, bitmap=bmq))
+run("Q6 conjunction, 3 columns (3 launches)", "fle_pred_w_kernel<12, 1>", q6.algorithmic_bytes(nq), lambda: capi.eval_program(nodes, cols, nq, bitmap=bmq))
