@@ -318,10 +318,15 @@ __device__ __forceinline__ void fle_scan_body(
           } else {
             x = lds8[src * kStride + 4u * ((31u - j) & 7u) + ((31u - j) >> 3)];
           }
+#ifndef IPS_NT_VALUE_STORE
+#define IPS_NT_VALUE_STORE 0
+#endif
           if (G == 0) {
-            dst[i] = (GT)x;
+            if (IPS_NT_VALUE_STORE) __builtin_nontemporal_store((GT)x, dst + i);
+            else dst[i] = (GT)x;
           } else if (x < dict_entries) {
-            dst[i] = lookup(x);
+            if (IPS_NT_VALUE_STORE) __builtin_nontemporal_store(lookup(x), dst + i);
+            else dst[i] = lookup(x);
           } else {
             bad = 1;
           }
