@@ -41,6 +41,7 @@ SYMBOLS = [
     "ips_dict_open", "ips_dict_close", "ips_dict_num_entries", "ips_dict_bit_width", "ips_dict_encode",
     "ips_dict_encode_workspace_bytes", "ips_program_workspace_bytes",
     "ips_nullable_workspace_bytes", "ips_fle_pred_nullable", "ips_dict_pred_nullable",
+    "ips_select_nullable_workspace_bytes", "ips_dict_select_nullable",
     "ips_dict_translate", "ips_dict_pred", "ips_dict_decode", "ips_dict_scan", "ips_dict_select",
     "ips_plain_stride", "ips_plain_pred", "ips_plain_scan", "ips_plain_select",
     "ips_bitmap_and", "ips_bitmap_or", "ips_bitmap_fill", "ips_bitmap_count",
@@ -372,6 +373,26 @@ def _dict_pred_nullable(self, def_levels, def_bw, max_def, n_rows, codes_enc, n_
 
 
 Dict.pred_nullable = _dict_pred_nullable
+
+
+def select_nullable(dict_, def_levels, def_bw, max_def, n_rows, codes_enc, n_data_rows, bw, selection, stream=None):
+    """One-call late materialisation of an OPTIONAL column (dict_ may be None: raw FLE values).
+    -> (dense values of the selected non-NULL rows, NOT-NULL flag words per selected row,
+        n_selected, n_selected_non_null)"""
+    dev = def_levels.device
+    vw = 4 if dict_ is None else torch.empty(0, dtype=TORCH_SLOT[dict_.type]).element_size()
+    lib().ips_select_nullable_workspace_bytes.restype = C.c_size_t
+    ws = torch.empty(int(lib().ips_select_nullable_workspace_bytes(C.c_int64(n_rows), C.c_int64(n_data_rows), vw)) + 16,
+                     dtype=torch.uint8, device=dev)
+    dense = torch.empty(max(n_data_rows, 16), dtype=torch.int32 if dict_ is None else TORCH_SLOT[dict_.type], device=dev)
+    flags = torch.empty(max(_words(n_rows), 2), dtype=torch.int64, device=dev)
+    counts = torch.zeros(2, dtype=torch.int64, device=dev)
+    _ck(lib().ips_dict_select_nullable(dict_.h if dict_ is not None else None, _ptr(def_levels), def_bw, max_def,
+                                       C.c_int64(n_rows), _ptr(codes_enc), C.c_int64(n_data_rows), bw,
+                                       _ptr(selection), _ptr(dense), _ptr(flags), _ptr(counts), _ptr(ws),
+                                       _stream(stream)))
+    n_sel, n_val = (int(x) for x in counts.cpu().tolist())
+    return dense[:n_val], flags[:_words(max(n_sel, 1))], n_sel, n_val
 
 
 def _dict_select(self, codes_enc, n_rows, bw, bitmap, stream=None):

@@ -793,6 +793,92 @@ ips_status ips_dict_select(const ips_dict* dict, const void* d_codes_enc, int64_
                          d_batch_counts, dict->d_entries, (uint32_t)dict->n, nullptr, S(stream));
 }
 
+// ---- OPTIONAL column: late materialisation in one call ---------------------------------------
+namespace {
+struct SelNullWs {
+  uint32_t* rank;        // tile counts (used by one compress at a time)
+  uint64_t* nonnull;     // NOT-NULL bitmap when the levels are wider than a bit
+  uint64_t* data_sel;    // the selection over the data rows
+  uint8_t* batch_values; // per-batch values of the selected data rows
+  uint32_t* batch_counts;
+  uint8_t* compact_ws;
+  size_t total;
+};
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+SelNullWs sel_null_ws(void* base, int64_t n_rows, int64_t n_data_rows, int value_width) {
+  const size_t bm = align256((size_t)((n_rows + 63) / 64) * 8);
+  const int64_t nb = n_batches_of(n_data_rows > 0 ? n_data_rows : 1);
+  uint8_t* p = reinterpret_cast<uint8_t*>(base);
+  SelNullWs w;
+  size_t off = 0;
+  w.rank = reinterpret_cast<uint32_t*>(p + off); off += rank_workspace_bytes(n_rows);
+  w.nonnull = reinterpret_cast<uint64_t*>(p + off); off += bm;
+  w.data_sel = reinterpret_cast<uint64_t*>(p + off); off += bm;
+  w.batch_values = p + off; off += align256((size_t)nb * IPS_BATCH_ROWS * (size_t)value_width);
+  w.batch_counts = reinterpret_cast<uint32_t*>(p + off); off += align256((size_t)nb * 4);
+  w.compact_ws = p + off; off += align256(batches_workspace_bytes(nb));
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+size_t ips_select_nullable_workspace_bytes(int64_t n_rows, int64_t n_data_rows, int value_width) {
+  if (n_rows < 0 || n_data_rows < 0 || (value_width != 4 && value_width != 8)) return 0;
+  return sel_null_ws(nullptr, n_rows, n_data_rows, value_width).total;
+}
+
+ips_status ips_dict_select_nullable(const ips_dict* dict, const void* d_def_levels, int def_bit_width,
+                                    int max_def_level, int64_t n_rows, const void* d_codes_enc,
+                                    int64_t n_data_rows, int bit_width, const uint64_t* d_selection,
+                                    void* d_dense_values, uint64_t* d_nonnull_flags, int64_t* d_counts,
+                                    void* d_workspace, ips_stream stream) {
+  ips_status st = check_nullable(d_def_levels, def_bit_width, max_def_level, n_rows, n_data_rows,
+                                 d_nonnull_flags, d_workspace, "ips_dict_select_nullable");
+  if (st != IPS_OK) return st;
+  if (!check_fle_common(d_codes_enc, n_data_rows, bit_width, "ips_dict_select_nullable")) return IPS_ERR_INVALID_ARG;
+  IPS_REQUIRE(!dict || bit_width <= 16, "ips_dict_select_nullable: code width %d > 16", bit_width);
+  IPS_REQUIRE(d_counts != nullptr, "ips_dict_select_nullable: NULL counts");
+  IPS_REQUIRE(n_rows == 0 || (d_selection && aligned16(d_selection) && d_dense_values && aligned16(d_dense_values)),
+              "ips_dict_select_nullable: NULL or misaligned argument");
+  hipStream_t s = S(stream);
+  if (n_rows == 0) {
+    IPS_HIP_TRY(hipMemsetAsync(d_counts, 0, 16, s));
+    return IPS_OK;
+  }
+  const int vw = dict ? dict->slot : 4;
+  const SelNullWs w = sel_null_ws(d_workspace, n_rows, n_data_rows, vw);
+  NullableWs nws;
+  nws.tile_counts = w.rank;
+  nws.sub = w.data_sel;
+  nws.nonnull = w.nonnull;
+  int root_kind = 0;
+  const uint64_t* root = nullptr;
+  st = nullable_prepare_root(d_def_levels, def_bit_width, max_def_level, n_rows, nws, &root_kind, &root, s);
+  if (st != IPS_OK) return st;
+  // 1. the selection over the DATA rows (the rows ReadValue decodes once ReadDefinitionLevel said
+  //    non-NULL, hdfs-parquet-scanner.cc:1009-1014)
+  st = launch_compress(root_kind, root, 0, d_selection, n_rows, w.data_sel, nullptr, w.rank, s);
+  if (st != IPS_OK) return st;
+  // 2. their values, per batch, then dense in row order
+  const int64_t n_data = n_data_rows < n_rows ? n_data_rows : n_rows;
+  if (n_data > 0) {
+    PredArgs args;
+    memset(&args, 0, sizeof(args));
+    st = launch_fle_scan(bit_width, kScanGivenBitmap, dict ? dict->slot : 0,
+                         reinterpret_cast<const uint64_t*>(d_codes_enc), n_data, args, nullptr,
+                         reinterpret_cast<const uint32_t*>(w.data_sel), w.batch_values, w.batch_counts,
+                         dict ? dict->d_entries : nullptr, dict ? (uint32_t)dict->n : 0u, nullptr, s);
+    if (st != IPS_OK) return st;
+    st = launch_batches_compact(w.batch_values, w.batch_counts, n_batches_of(n_data), vw, d_dense_values,
+                                d_counts + 1, w.compact_ws, s);
+    if (st != IPS_OK) return st;
+  } else {
+    IPS_HIP_TRY(hipMemsetAsync(d_counts + 1, 0, 8, s));
+  }
+  // 3. the NOT-NULL flag of every selected row (the NULL indicator bit, :1022-1026)
+  return launch_compress(0, d_selection, root_kind, root, n_rows, d_nonnull_flags, d_counts, w.rank, s);
+}
+
 // ---- PLAIN ----------------------------------------------------------------------------------
 int ips_plain_stride(ips_type type) {
   switch (type) {

@@ -72,6 +72,9 @@ ips_status launch_expand(int root_kind, const uint64_t* root, const uint64_t* su
                          int64_t n_sub_bits, const uint32_t* tile_counts, uint64_t* out,
                          int combine, hipStream_t s);
 ips_status launch_bitmap_fill(uint64_t* a, int64_t n_rows, int value, hipStream_t s);
+ips_status launch_compress(int mask_kind, const uint64_t* mask, int src_kind, const uint64_t* src,
+                           int64_t n_rows, uint64_t* out, int64_t* n_out, uint32_t* tile_counts,
+                           hipStream_t s);
 
 // Workspace of a nullable predicate leaf: tile counts | data-row bitmap | NOT-NULL bitmap (the
 // last only when the definition levels are wider than one bit).

@@ -632,115 +632,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_of_totals_kernel(uint64_t* 
   }
 }
 
-// ---- IntersectBitset ------------------------------------------------------------------------
-// Bit deposit / extract of a 64-bit word (pdep / pext), four mask bits at a time through a 256-entry
-// table in LDS: entry [mask4 << 4 | src4] = the nibble's result.  16 independent table reads per
-// word instead of a loop of up to 64 dependent steps.
-__device__ __forceinline__ void nibble_tables_init(uint8_t* dep, uint8_t* ext) {
-  // called by all kScanThreads (= 256) threads: one entry each
-  const uint32_t m = threadIdx.x >> 4, v = threadIdx.x & 15u;
-  uint32_t d = 0, e = 0, j = 0;
-#pragma unroll
-  for (uint32_t bit = 0; bit < 4; ++bit) {
-    if (m & (1u << bit)) {
-      if (v & (1u << j)) d |= 1u << bit;   // deposit: j-th source bit goes to mask position 'bit'
-      if (v & (1u << bit)) e |= 1u << j;   // extract: source bit at 'bit' becomes result bit j
-      ++j;
-    }
-  }
-  dep[threadIdx.x] = (uint8_t)d;
-  ext[threadIdx.x] = (uint8_t)e;
-  __syncthreads();
-}
-
-__device__ __forceinline__ uint64_t deposit_bits(uint64_t src, uint64_t mask, const uint8_t* dep) {
-  uint32_t out[2] = {0u, 0u};
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const uint32_t mh = (uint32_t)(mask >> (32 * h));
-#pragma unroll
-    for (int n = 0; n < 8; ++n) {
-      const uint32_t m4 = (mh >> (4 * n)) & 15u;
-      const uint32_t r = dep[(m4 << 4) | ((uint32_t)src & 15u)];
-      out[h] |= r << (4 * n);
-      src >>= __builtin_popcount(m4);
-    }
-  }
-  return (uint64_t)out[0] | ((uint64_t)out[1] << 32);
-}
-
-// (IntersectBitset itself -- expand -- lives in ips_rank.hip.)
-
-// ---- bitmap compress (inverse of IntersectBitset) ---------------------------------------------
-__device__ __forceinline__ uint64_t extract_bits(uint64_t src, uint64_t mask, const uint8_t* ext) {
-  uint64_t out = 0;
-  uint32_t pos = 0;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const uint32_t mh = (uint32_t)(mask >> (32 * h)), sh = (uint32_t)(src >> (32 * h));
-#pragma unroll
-    for (int n = 0; n < 8; ++n) {
-      const uint32_t m4 = (mh >> (4 * n)) & 15u;
-      const uint32_t r = ext[(m4 << 4) | ((sh >> (4 * n)) & 15u)];
-      out |= (uint64_t)r << pos;
-      pos += __builtin_popcount(m4);
-    }
-  }
-  return out;
-}
-
-__global__ __launch_bounds__(kScanThreads) void bitmap_compress_kernel(
-    const uint64_t* __restrict__ mask, const uint64_t* __restrict__ src, int64_t n_rows,
-    const uint64_t* __restrict__ block_offsets, unsigned long long* __restrict__ out) {
-  __shared__ uint8_t dep_lut[256], ext_lut[256];
-  nibble_tables_init(dep_lut, ext_lut);
-  const int64_t n_words = (n_rows + 63) / 64;
-  const int64_t base = (int64_t)blockIdx.x * kScanItems + (int64_t)threadIdx.x * kScanPerThread;
-  PopcItems items{mask, n_rows};
-  uint32_t pc[kScanPerThread];
-  uint32_t v = 0;
-#pragma unroll
-  for (int e = 0; e < kScanPerThread; ++e) {
-    pc[e] = base + e < n_words ? items(base + e) : 0u;
-    v += pc[e];
-  }
-  uint32_t total;
-  uint64_t off = block_offsets[blockIdx.x] + block_exclusive_scan(v, &total);
-#pragma unroll
-  for (int e = 0; e < kScanPerThread; ++e) {
-    if (base + e < n_words && pc[e]) {
-      uint64_t m = mask[base + e];
-      int64_t valid = n_rows - (base + e) * 64;
-      if (valid < 64) m &= (1ull << valid) - 1ull;
-      const uint64_t bits = extract_bits(src[base + e], m, ext_lut);
-      const int sh = (int)(off & 63);
-      if (bits) {  // neighbouring threads share output words: OR the pieces in (out is zeroed)
-        atomicOr(out + (off >> 6), bits << sh);
-        if (sh && (bits >> (64 - sh))) atomicOr(out + (off >> 6) + 1, bits >> (64 - sh));
-      }
-      off += pc[e];
-    }
-  }
-}
-
-ips_status launch_bitmap_compress(const uint64_t* mask, const uint64_t* src, int64_t n_rows,
-                                  uint64_t* out, int64_t* n_out, void* workspace, hipStream_t s) {
-  const int64_t n_words = (n_rows + 63) / 64;
-  if (n_words <= 0) {
-    if (n_out) IPS_HIP_TRY(hipMemsetAsync(n_out, 0, 8, s));
-    return IPS_OK;
-  }
-  IPS_HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_words * 8, s));
-  const int64_t nb = (n_words + kScanItems - 1) / kScanItems;
-  uint64_t* totals = reinterpret_cast<uint64_t*>(workspace);
-  hipLaunchKernelGGL((scan_block_totals_kernel<PopcItems>), dim3((unsigned)nb), dim3(kScanThreads),
-                     0, s, PopcItems{mask, n_rows}, n_words, totals);
-  hipLaunchKernelGGL(scan_of_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, totals, nb, n_out);
-  hipLaunchKernelGGL(bitmap_compress_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, s, mask, src,
-                     n_rows, totals, reinterpret_cast<unsigned long long*>(out));
-  IPS_HIP_TRY(hipGetLastError());
-  return IPS_OK;
-}
+// (IntersectBitset -- expand -- and its inverse, compress, live in ips_rank.hip.)
 
 // exclusive prefix popcount per bitmap word (rank support for the NULL flags of selected rows)
 __global__ __launch_bounds__(kScanThreads) void word_prefix_kernel(

@@ -66,9 +66,12 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
   return __builtin_amdgcn_readlane(wave_inclusive_scan(x), 63);
 }
 
-template <int ROOT>
+// ZERO: also clears the words of 'zero_out' that belong to the tile (the compress output must start
+// as zeros where two waves share a word; clearing it here saves a memset launch)
+template <int ROOT, bool ZERO>
 __global__ __launch_bounds__(kRankThreads) void rank_tile_counts_kernel(
-    const u64* __restrict__ root, int64_t n_rows, uint32_t* __restrict__ tile_counts) {
+    const u64* __restrict__ root, int64_t n_rows, uint32_t* __restrict__ tile_counts,
+    u64* __restrict__ zero_out) {
   __shared__ uint32_t wave_tot[kRankThreads / kWave];
   const int lane = lane_id();
   const int wave = wave_id();
@@ -76,6 +79,18 @@ __global__ __launch_bounds__(kRankThreads) void rank_tile_counts_kernel(
   const int64_t first = (int64_t)blockIdx.x * kRankWordsPerTile + wave * kRankWordsPerWave;
   u64 m[kRankRounds][2];
   load_root<ROOT>(root, first, n_words, n_rows, lane, m);
+  if (ZERO) {
+#pragma unroll
+    for (int r = 0; r < kRankRounds; ++r) {
+      const int64_t w0 = first + r * 128 + 2 * lane;
+      if (w0 + 1 < n_words) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(zero_out + w0) = z;
+      } else if (w0 < n_words) {
+        zero_out[w0] = 0ull;
+      }
+    }
+  }
   uint32_t c = 0;
 #pragma unroll
   for (int r = 0; r < kRankRounds; ++r) c += __builtin_popcountll(m[r][0]) + __builtin_popcountll(m[r][1]);
@@ -216,9 +231,9 @@ ips_status launch_rank_tile_counts(int root_kind, const uint64_t* root, int64_t 
   if (tiles <= 0) return IPS_OK;
   const u64* r = reinterpret_cast<const u64*>(root);
   if (root_kind == kRootLevels1)
-    hipLaunchKernelGGL(rank_tile_counts_kernel<kRootLevels1>, dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, n_rows, tile_counts);
+    hipLaunchKernelGGL((rank_tile_counts_kernel<kRootLevels1, false>), dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, n_rows, tile_counts, (u64*)nullptr);
   else
-    hipLaunchKernelGGL(rank_tile_counts_kernel<kRootBitmap>, dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, n_rows, tile_counts);
+    hipLaunchKernelGGL((rank_tile_counts_kernel<kRootBitmap, false>), dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, n_rows, tile_counts, (u64*)nullptr);
   IPS_HIP_TRY(hipGetLastError());
   return IPS_OK;
 }
@@ -247,6 +262,160 @@ ips_status launch_bitmap_expand(const uint64_t* root, const uint64_t* sub, int64
   ips_status st = launch_rank_tile_counts(kRootBitmap, root, n_rows, counts, s);
   if (st != IPS_OK) return st;
   return launch_expand(kRootBitmap, root, sub, n_rows, n_rows, counts, out, 0, s);
+}
+
+// ---- compress: the inverse of IntersectBitset ------------------------------------------------
+// out bit j = src bit at the position of the j-th set bit of mask.  Same tiles and ranks as expand;
+// per word the selected source bits are extracted (pext, four mask bits at a time through the
+// table) and OR-ed into the wave's output segment, which is assembled in LDS (ds_or_b64: the
+// pieces of neighbouring lanes share words) and leaves as whole words; only the first and the last
+// word of a wave's segment can be shared with another wave and go out as global atomics (the
+// output was cleared by the counting pass).  Round 1 issued two global atomics per input word.
+__device__ __forceinline__ void extract_lut_init(uint8_t* lut) {  // 256 threads: one entry each
+  const uint32_t m = threadIdx.x >> 4, v = threadIdx.x & 15u;
+  uint32_t e = 0, j = 0;
+#pragma unroll
+  for (uint32_t bit = 0; bit < 4; ++bit) {
+    if (m & (1u << bit)) {
+      if (v & (1u << bit)) e |= 1u << j;
+      ++j;
+    }
+  }
+  lut[threadIdx.x] = (uint8_t)e;
+}
+
+__device__ __forceinline__ u64 extract64(u64 src, u64 mask, const uint8_t* __restrict__ lut) {
+  u64 out = 0;
+  uint32_t pos = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t mh = (uint32_t)(mask >> (32 * h)), sh = (uint32_t)(src >> (32 * h));
+    uint32_t o = 0, rank = 0;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const uint32_t m4 = (mh >> (4 * n)) & 15u;
+      const uint32_t s4 = (sh >> (4 * n)) & 15u;
+      o |= (uint32_t)lut[(m4 << 4) | s4] << rank;  // rank <= 28, the piece has <= 4 bits
+      rank += (uint32_t)__builtin_popcount(m4);
+    }
+    out |= (u64)o << pos;
+    pos += rank;
+  }
+  return out;
+}
+
+constexpr int kSegWords = kRankWordsPerWave + 2;  // a wave's output segment: <= 65536 bits + misalignment
+
+template <int MASK, int SRC>
+__global__ __launch_bounds__(kRankThreads) void compress_kernel(
+    const u64* __restrict__ mask, const u64* __restrict__ src, int64_t n_rows,
+    const uint32_t* __restrict__ tile_counts, u64* __restrict__ out, int64_t* __restrict__ n_out) {
+  __shared__ uint8_t lut[256];
+  __shared__ u64 part[kRankThreads / kWave];
+  __shared__ uint32_t wave_tot[kRankThreads / kWave];
+  __shared__ __attribute__((aligned(16))) u64 seg_all[(kRankThreads / kWave) * kSegWords];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int64_t n_words = (n_rows + 63) / 64;
+  extract_lut_init(lut);
+  u64* seg = seg_all + wave * kSegWords;
+  for (int i = lane; i < kSegWords; i += kWave) seg[i] = 0ull;
+  u64 before = 0;
+  for (int64_t i = threadIdx.x; i < (int64_t)blockIdx.x; i += kRankThreads) before += tile_counts[i];
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
+  if (lane == 0) part[wave] = before;
+
+  const int64_t first = (int64_t)blockIdx.x * kRankWordsPerTile + wave * kRankWordsPerWave;
+  u64 m[kRankRounds][2], sv[kRankRounds][2];
+  load_root<MASK>(mask, first, n_words, n_rows, lane, m);
+  load_root<SRC>(src, first, n_words, n_rows, lane, sv);
+  uint32_t excl[kRankRounds];
+  uint32_t run = 0;
+#pragma unroll
+  for (int r = 0; r < kRankRounds; ++r) {
+    const uint32_t c = (uint32_t)(__builtin_popcountll(m[r][0]) + __builtin_popcountll(m[r][1]));
+    const uint32_t incl = wave_inclusive_scan(c);
+    excl[r] = run + incl - c;
+    run += __builtin_amdgcn_readlane(incl, 63);
+  }
+  if (lane == 0) wave_tot[wave] = run;
+  __syncthreads();
+  u64 base = part[0] + part[1] + part[2] + part[3];
+  for (int w = 0; w < wave; ++w) base += wave_tot[w];
+  if (n_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == kRankThreads - 1)
+    *n_out = (int64_t)(base + run);  // last wave of the last tile: popcount(mask)
+
+  const uint32_t lead = (uint32_t)(base & 63);  // the segment starts inside global word base >> 6
+#pragma unroll
+  for (int r = 0; r < kRankRounds; ++r) {
+    uint32_t o = lead + excl[r];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const u64 mk = m[r][e];
+      const uint32_t pc = (uint32_t)__builtin_popcountll(mk);
+      if (pc) {
+        const u64 bits = extract64(sv[r][e], mk, lut);
+        const uint32_t sh = o & 63u;
+        if (bits) {
+          __hip_atomic_fetch_or(&seg[o >> 6], bits << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (sh && (bits >> (64 - sh)))
+            __hip_atomic_fetch_or(&seg[(o >> 6) + 1], bits >> (64 - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+      }
+      o += pc;
+    }
+  }
+  wave_lds_fence();
+  // flush: global words [g0, g0 + nw) hold this wave's bits; the two end words may be shared
+  const int64_t g0 = (int64_t)(base >> 6);
+  const uint32_t nw = run ? (lead + run + 63) / 64 : 0;
+  for (uint32_t i = lane; i < nw; i += kWave) {
+    const u64 v = seg[i];
+    if (i == 0 || i == nw - 1) {
+      if (v) atomicOr(reinterpret_cast<unsigned long long*>(out + g0 + i), (unsigned long long)v);
+    } else {
+      out[g0 + i] = v;
+    }
+  }
+}
+
+template <int MASK>
+static void launch_compress_src(int src_kind, dim3 grid, hipStream_t s, const u64* mask, const u64* src,
+                                int64_t n_rows, const uint32_t* counts, u64* out, int64_t* n_out) {
+  if (src_kind == kRootLevels1)
+    hipLaunchKernelGGL((compress_kernel<MASK, kRootLevels1>), grid, dim3(kRankThreads), 0, s, mask, src, n_rows, counts, out, n_out);
+  else
+    hipLaunchKernelGGL((compress_kernel<MASK, kRootBitmap>), grid, dim3(kRankThreads), 0, s, mask, src, n_rows, counts, out, n_out);
+}
+
+// mask_kind / src_kind: kRootBitmap or kRootLevels1 (width-1 definition levels used as NOT-NULL bits)
+ips_status launch_compress(int mask_kind, const uint64_t* mask, int src_kind, const uint64_t* src,
+                           int64_t n_rows, uint64_t* out, int64_t* n_out, uint32_t* tile_counts,
+                           hipStream_t s) {
+  const int64_t tiles = rank_tiles(n_rows);
+  if (tiles <= 0) {
+    if (n_out) IPS_HIP_TRY(hipMemsetAsync(n_out, 0, 8, s));
+    return IPS_OK;
+  }
+  const u64* mk = reinterpret_cast<const u64*>(mask);
+  const u64* sr = reinterpret_cast<const u64*>(src);
+  u64* o = reinterpret_cast<u64*>(out);
+  const dim3 grid((unsigned)tiles);
+  if (mask_kind == kRootLevels1) {
+    hipLaunchKernelGGL((rank_tile_counts_kernel<kRootLevels1, true>), grid, dim3(kRankThreads), 0, s, mk, n_rows, tile_counts, o);
+    launch_compress_src<kRootLevels1>(src_kind, grid, s, mk, sr, n_rows, tile_counts, o, n_out);
+  } else {
+    hipLaunchKernelGGL((rank_tile_counts_kernel<kRootBitmap, true>), grid, dim3(kRankThreads), 0, s, mk, n_rows, tile_counts, o);
+    launch_compress_src<kRootBitmap>(src_kind, grid, s, mk, sr, n_rows, tile_counts, o, n_out);
+  }
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+ips_status launch_bitmap_compress(const uint64_t* mask, const uint64_t* src, int64_t n_rows,
+                                  uint64_t* out, int64_t* n_out, void* workspace, hipStream_t s) {
+  return launch_compress(kRootBitmap, mask, kRootBitmap, src, n_rows, out, n_out,
+                         reinterpret_cast<uint32_t*>(workspace), s);
 }
 
 // ---- nullable predicate leaf: workspace + NOT-NULL root -------------------------------------

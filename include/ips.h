@@ -276,6 +276,23 @@ ips_status ips_dict_select(const ips_dict* dict, const void* d_codes_enc, int64_
                            int bit_width, const uint64_t* d_bitmap, void* d_batch_values,
                            uint32_t* d_batch_counts, ips_stream stream);
 
+/* Late materialisation of an OPTIONAL column against a selection bitmap, in one call: the
+ * ReadDefinitionLevel walk + GetValue(skip) of the selected non-NULL rows that ReadValue(skip) does
+ * per row (hdfs-parquet-scanner.cc:1006-1038, 927-979).  Produces exactly what an OPTIONAL
+ * ips_tuple_column takes:
+ *   d_dense_values    the values of the selected NON-NULL rows, dense, in row order (dictionary
+ *                     entries of ips slot width when dict != NULL, else the raw 4-byte FLE values)
+ *   d_nonnull_flags   one bit per SELECTED row, 1 = not NULL (ceil(n_rows/64) words reserved)
+ *   d_counts          int64[2]: [0] selected rows, [1] selected non-NULL rows
+ * d_def_levels / n_data_rows as in ips_fle_pred_nullable; d_selection: ceil(n_rows/64) words.
+ * Workspace: ips_select_nullable_workspace_bytes(n_rows, n_data_rows, value_width 4 | 8). */
+size_t ips_select_nullable_workspace_bytes(int64_t n_rows, int64_t n_data_rows, int value_width);
+ips_status ips_dict_select_nullable(const ips_dict* dict, const void* d_def_levels, int def_bit_width,
+                                    int max_def_level, int64_t n_rows, const void* d_codes_enc,
+                                    int64_t n_data_rows, int bit_width, const uint64_t* d_selection,
+                                    void* d_dense_values, uint64_t* d_nonnull_flags, int64_t* d_counts,
+                                    void* d_workspace, ips_stream stream);
+
 /* ---- PLAIN fixed-width pages ---------------------------------------------------------------- */
 /* ParquetPlainEncoder::ByteSize(ColumnType), parquet-common.h:92-117: 4 or 8 */
 int ips_plain_stride(ips_type type);

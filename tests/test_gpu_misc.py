@@ -176,12 +176,14 @@ def test_nullable_dictionary_column(capi, O):
     dd.close()
 
 
-@pytest.mark.parametrize("strategy", ["auto", "general"])
+@pytest.mark.parametrize("strategy", ["auto", "general", "one_pass"])
 def test_fused_program(capi, O, strategy, monkeypatch):
     """EvalSimplePredicates over several columns vs numpy: BETWEEN = And(Ge, Le); And(Gt a, Lt b);
     Or; IN; PLAIN leaves (int32, int64, double).  'auto' lets ips_eval_program use the
     per-operand plan (stand-alone predicate kernels on a stack of bitmaps); 'general' forces the one-launch
     program kernel for every tree."""
+    if strategy == "one_pass":   # chains of <= 4 operands run as the one-pass kernel, the rest as planned
+        monkeypatch.setenv("IPS_PROGRAM_ONE_PASS", "1")
     if strategy == "general":
         monkeypatch.setenv("IPS_PROGRAM_NO_CHAIN", "1")
     else:
@@ -372,6 +374,14 @@ def test_nullable_column_materialisation(capi, O):
     got_opt = t[:, 4:8].copy().view(np.int32).ravel()
     assert np.array_equal(got_opt[~nulls], full[sel_np][~nulls])
     assert not got_opt[nulls].any()                               # NULL slots untouched (zero)
+    # the same in ONE call per OPTIONAL column (ips_dict_select_nullable), also on the level words
+    n_data_blocks = ((n_data + 63) // 64) * 64
+    dense1, flags1, n_sel1, n_val1 = capi.select_nullable(dd, defs, 1, 1, n, dev_words(blocks), n_data_blocks, bw, sel)
+    assert n_sel1 == n_sel and n_val1 == dense.numel()
+    assert torch.equal(dense1, dense)
+    assert torch.equal(flags1[:(n_sel + 63) // 64], flags[:(n_sel + 63) // 64])
+    tuples1 = capi.assemble_tuples([(va, 0), (dense1, 4, flags1, 8, 0x01)], counts, n, tuple_size)
+    assert torch.equal(tuples1, tuples)
     dd.close()
 
 
@@ -414,11 +424,13 @@ def test_dict_encode_on_gpu(capi, O, type_name):
             capi.dict_encode(big, t)
 
 
-@pytest.mark.parametrize("strategy", ["auto", "general"])
+@pytest.mark.parametrize("strategy", ["auto", "general", "one_pass"])
 def test_random_predicate_trees(capi, O, strategy, monkeypatch):
     """Random AND/OR trees (up to 12 leaves, any shape) over FLE and PLAIN columns against numpy:
     exercises the per-operand planner's bitmap stack (which bitmap ends up as the root, temporaries,
     same-column pairs, IN leaves) and the one-launch interpreter on the same programs."""
+    if strategy == "one_pass":   # chains of <= 4 operands run as the one-pass kernel, the rest as planned
+        monkeypatch.setenv("IPS_PROGRAM_ONE_PASS", "1")
     if strategy == "general":
         monkeypatch.setenv("IPS_PROGRAM_NO_CHAIN", "1")
     else:
