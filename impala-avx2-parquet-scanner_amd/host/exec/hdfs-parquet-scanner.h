@@ -31,6 +31,19 @@ class HdfsParquetScanner {
     virtual ~BaseColumnReader() {}
     virtual bool SkipValue(int skip_rows) = 0;
     virtual bool LowerLeaf(int op, const void* lits, int n_lits, ips_column* col, ips_node* node) = 0;
+    // facade extra (AssembleRowsFused): materialise the rows selected by d_selection (num_rows rows
+    // of the current page) on the device and describe them as one ips_tuple_column.  'keep' holds
+    // the device buffers until the tuples have been assembled.
+    struct Materialised {
+      std::vector<std::unique_ptr<ips::DeviceBuffer>> keep;
+      ips::DeviceBuffer& add(size_t bytes) {
+        keep.emplace_back(new ips::DeviceBuffer(bytes));
+        return *keep.back();
+      }
+      ips::DeviceBuffer counts;  // batch counts of the selection (shared by all REQUIRED columns)
+    };
+    virtual bool SelectInto(int64_t num_rows, const uint64_t* d_selection, ips_tuple_column* col,
+                            Materialised* m) = 0;
     int64_t num_buffered_values() const { return num_buffered_values_; }
     void consume(int64_t n) { num_buffered_values_ -= n; }
     int max_def_level() const { return max_def_level_; }
@@ -188,6 +201,49 @@ class HdfsParquetScanner {
       node->op = op;
       node->n_consts = n_lits;
       for (int i = 0; i < n_lits; ++i) memcpy(&node->consts[i], (const T*)lits + i, sizeof(T));
+      return true;
+    }
+
+    // ReadValue(skip) of every selected row at once (.cc:1151-1181, 1006-1027): dictionary pages
+    // through ips_dict_select / ips_dict_select_nullable, PLAIN pages through ips_plain_select.
+    virtual bool SelectInto(int64_t num_rows, const uint64_t* d_selection, ips_tuple_column* col,
+                            Materialised* m) {
+      memset(col, 0, sizeof(*col));
+      const ips_type t = IpsTypeOf<T>::value;
+      const int vw = ips_plain_stride(t);
+      col->value_width = vw;
+      const int64_t nb = (num_rows + IPS_BATCH_ROWS - 1) / IPS_BATCH_ROWS;
+      if (dict_decoder_ && max_def_level_ > 0) {
+        if (!fle_def_levels_ || !fle_def_levels_->usable()) return false;
+        const int64_t n_data = dict_decoder_->codes()->rows_in_buffer();
+        ips::DeviceBuffer& dense = m->add((size_t)std::max<int64_t>(n_data, 16) * vw);
+        ips::DeviceBuffer& flags = m->add((size_t)((num_rows + 63) / 64 + 2) * 8);
+        ips::DeviceBuffer& cnt = m->add(16);
+        ips::DeviceBuffer& ws = m->add(ips_select_nullable_workspace_bytes(num_rows, n_data, vw));
+        if (!ips::ok(ips_dict_select_nullable(dict_decoder_->handle(), fle_def_levels_->device_blocks(),
+                                              fle_def_levels_->bit_width(), max_def_level_, num_rows,
+                                              dict_decoder_->codes()->device_blocks(), n_data,
+                                              dict_decoder_->code_bit_width(), d_selection, dense.get(),
+                                              flags.as<uint64_t>(), cnt.as<int64_t>(), ws.get(), nullptr),
+                     "ips_dict_select_nullable"))
+          return false;
+        col->d_dense_values = dense.get();
+        col->d_nonnull_flags = flags.as<uint64_t>();
+        return true;
+      }
+      ips::DeviceBuffer& values = m->add((size_t)nb * IPS_BATCH_ROWS * vw);
+      if (!m->counts.get() && !m->counts.resize((size_t)nb * 4)) return false;
+      ips_status st;
+      if (dict_decoder_) {
+        st = ips_dict_select(dict_decoder_->handle(), dict_decoder_->codes()->device_blocks(), num_rows,
+                             dict_decoder_->code_bit_width(), d_selection, values.get(),
+                             m->counts.as<uint32_t>(), nullptr);
+      } else {
+        if (!EnsurePlainResident()) return false;
+        st = ips_plain_select(plain_dev_.get(), num_rows, t, d_selection, values.get(), m->counts.as<uint32_t>(), nullptr);
+      }
+      if (!ips::ok(st, "select")) return false;
+      col->d_batch_values = values.get();
       return true;
     }
 
@@ -479,6 +535,82 @@ class HdfsParquetScanner {
                                     ws_bytes ? program_workspace_.get() : nullptr, nullptr),
                    "ips_eval_program") &&
            bm.download(bitmap_words->data(), bitmap_words->size() * 8);
+  }
+
+  // facade extra: AssembleRows' vector path (.cc:1101-1182) for num_rows rows of the current pages
+  // in a handful of launches -- the conjunct list (ips_eval_program), every slot's late
+  // materialisation against the resulting bitmap, and the row-major tuples (ips_assemble_tuples:
+  // InitTuple(template_tuple_) + each column's ReadValue at slot_desc->tuple_offset(), NULL
+  // indicator bits for OPTIONAL columns, descriptors.h:60-95).  Slots: 4- and 8-byte types.
+  struct SlotDesc {
+    int col_idx;            // column reader
+    int tuple_offset;       // SlotDescriptor::tuple_offset()
+    int null_byte_offset;   // null_indicator_offset().byte_offset (OPTIONAL columns)
+    int null_bit_mask;      // null_indicator_offset().bit_mask
+  };
+  bool AssembleRowsFused(int64_t num_rows, int tuple_size, const uint8_t* template_tuple,
+                         const std::vector<SlotDesc>& slots, std::vector<uint8_t>* tuples,
+                         int64_t* num_tuples) {
+    if (slots.empty() || slots.size() > IPS_TUPLE_MAX_COLS) return false;
+    std::vector<uint64_t> words;
+    lower_cols_.clear();
+    std::vector<ips_node> program;
+    for (size_t i = 0; i < simple_predicates_.size(); ++i) {
+      if (!simple_predicates_[i]->Lower(this, &program)) return false;
+      if (i > 0) { ips_node n; memset(&n, 0, sizeof(n)); n.kind = IPS_NODE_AND; program.push_back(n); }
+    }
+    ips::DeviceBuffer bm((size_t)((num_rows + 63) / 64 + 2) * 8);
+    if (program.empty()) {
+      if (!ips::ok(ips_bitmap_fill(bm.as<uint64_t>(), num_rows, 1, nullptr), "ips_bitmap_fill")) return false;
+    } else {
+      const size_t ws_bytes = ips_program_workspace_bytes(program.data(), (int)program.size(), lower_cols_.data(),
+                                                          (int)lower_cols_.size(), num_rows);
+      if (ws_bytes > 0 && !program_workspace_.resize(ws_bytes)) return false;
+      if (!ips::ok(ips_eval_program(program.data(), (int)program.size(), lower_cols_.data(), (int)lower_cols_.size(),
+                                    num_rows, bm.as<uint64_t>(), ws_bytes ? program_workspace_.get() : nullptr, nullptr),
+                   "ips_eval_program"))
+        return false;
+    }
+    BaseColumnReader::Materialised mat;
+    std::vector<ips_tuple_column> cols(slots.size());
+    int n_optional = 0;
+    for (size_t i = 0; i < slots.size(); ++i) {
+      BaseColumnReader* r = column_readers_[(size_t)slots[i].col_idx].get();
+      if (!r->SelectInto(num_rows, bm.as<uint64_t>(), &cols[i], &mat)) return false;
+      cols[i].tuple_offset = slots[i].tuple_offset;
+      if (cols[i].d_nonnull_flags) {
+        cols[i].null_byte_offset = slots[i].null_byte_offset;
+        cols[i].null_bit_mask = slots[i].null_bit_mask;
+        ++n_optional;
+      }
+    }
+    if (!mat.counts.get()) {  // only OPTIONAL slots: the batch counts come from the bitmap itself
+      const int64_t nb = (num_rows + IPS_BATCH_ROWS - 1) / IPS_BATCH_ROWS;
+      ips::DeviceBuffer dummy((size_t)nb * IPS_BATCH_ROWS * 4);
+      if (!mat.counts.resize((size_t)nb * 4)) return false;
+      // a width-1 column of zeros selected by the bitmap yields exactly the counts
+      ips::DeviceBuffer zeros((size_t)ips_fle_encoded_bytes(num_rows, 1) + 16);
+      if (!ips::ok(ips_memset(zeros.get(), 0, zeros.size(), nullptr), "ips_memset") ||
+          !ips::ok(ips_fle_select(zeros.get(), num_rows, 1, bm.as<uint64_t>(), dummy.as<uint32_t>(),
+                                  mat.counts.as<uint32_t>(), nullptr), "ips_fle_select"))
+        return false;
+    }
+    int64_t count = 0;
+    ips::DeviceBuffer d_count(16);
+    if (!ips::ok(ips_bitmap_count(bm.as<uint64_t>(), num_rows, d_count.as<int64_t>(), nullptr), "ips_bitmap_count") ||
+        !d_count.download(&count, 8))
+      return false;
+    ips::DeviceBuffer d_tuples((size_t)std::max<int64_t>(count, 1) * tuple_size + 64), d_total(16);
+    ips::DeviceBuffer ws(ips_assemble_workspace_bytes(num_rows, n_optional) + 64);
+    if (!ips::ok(ips_assemble_tuples(cols.data(), (int)cols.size(), mat.counts.as<uint32_t>(), num_rows, tuple_size,
+                                     template_tuple, d_tuples.get(), d_total.as<int64_t>(), ws.get(), nullptr),
+                 "ips_assemble_tuples"))
+      return false;
+    int64_t total = 0;
+    if (!d_total.download(&total, 8) || total != count) return false;
+    tuples->assign((size_t)total * tuple_size, 0);
+    *num_tuples = total;
+    return total == 0 || d_tuples.download(tuples->data(), tuples->size());
   }
 
   // used by LeafOperate::Lower: returns the column slot of the program for reader idx

@@ -669,6 +669,76 @@ static void TestColumnChunkStream() {
   }
 }
 
+// From the bytes of the column chunks to row-major tuples on the GPU: AddColumnChunk (the page
+// container), the conjunct list, every slot's late materialisation and the tuple assembly
+// (AssembleRows' vector path, hdfs-parquet-scanner.cc:1101-1182) -- against a row-at-a-time model
+// of InitTuple + ReadValue per selected row, NULL indicator bits included.
+static void TestAssembleRowsFused() {
+  const int n = 9000;  // one page per column: the fused path works on the current pages
+  std::vector<int32_t> c0(n), c2(n);
+  std::vector<int64_t> c1(n);
+  std::vector<bool> c1_null(n);
+  ColumnChunkWriter<int32_t> w0(parquet::CompressionCodec::GZIP, 0, 1 << 20);
+  ColumnChunkWriter<int64_t> w1(parquet::CompressionCodec::GZIP, 1, 1 << 20);
+  for (int i = 0; i < n; ++i) {
+    c0[i] = (int32_t)(rnd() % 1000);
+    c1_null[i] = (rnd() % 4) == 0;
+    c1[i] = (int64_t)(rnd() % 500) * 4000000007ll - 77;
+    c2[i] = (int32_t)(rnd() % 100000) - 50000;
+    CHECK(w0.AppendRow(&c0[i]));
+    CHECK(w1.AppendRow(c1_null[i] ? nullptr : &c1[i]));
+  }
+  std::vector<uint8_t> chunk0, chunk1, plain((size_t)n * 4);
+  CHECK(w0.Flush(&chunk0) && w1.Flush(&chunk1));
+  memcpy(plain.data(), c2.data(), plain.size());
+  HdfsParquetScanner scanner;
+  std::string err;
+  CHECK(scanner.AddColumnChunk<int32_t>(chunk0.data(), (int64_t)chunk0.size(), n, parquet::CompressionCodec::GZIP, 0, &err) == 0);
+  CHECK(scanner.AddColumnChunk<int64_t>(chunk1.data(), (int64_t)chunk1.size(), n, parquet::CompressionCodec::GZIP, 1, &err) == 1);
+  CHECK(scanner.AddPlainColumn<int32_t>(plain.data(), n) == 2);
+  scanner.AddSimplePredicate(scanner.Own(new AndOperate(scanner.Own(new GeOperate<int32_t>(0, 100)),
+                                                        scanner.Own(new LtOperate<int32_t>(0, 400)))));
+  // tuple: [int32 c0 @0][null byte @4][3 bytes of template][int64 c1 @8][int32 c2 @16][pad @20..23]
+  const int tuple_size = 24;
+  uint8_t tmpl[tuple_size];
+  for (int i = 0; i < tuple_size; ++i) tmpl[i] = (uint8_t)(0xA0 + i);
+  tmpl[4] = 0x40;  // other NULL-indicator bits of the byte survive
+  std::vector<HdfsParquetScanner::SlotDesc> slots = {{0, 0, 0, 0}, {1, 8, 4, 0x02}, {2, 16, 0, 0}};
+  for (int with_pred = 1; with_pred >= 0; --with_pred) {
+    if (!with_pred) scanner.ClearSimplePredicates();
+    std::vector<uint8_t> tuples;
+    int64_t n_tuples = -1;
+    CHECK(scanner.AssembleRowsFused(n, tuple_size, tmpl, slots, &tuples, &n_tuples));
+    int64_t k = 0, bad = 0;
+    for (int i = 0; i < n; ++i) {
+      if (with_pred && !(c0[i] >= 100 && c0[i] < 400)) continue;
+      if (k >= n_tuples) { ++bad; break; }
+      uint8_t expect[tuple_size];
+      memcpy(expect, tmpl, tuple_size);                 // InitTuple(template_tuple_, tuple)
+      memcpy(expect + 0, &c0[i], 4);
+      if (c1_null[i]) expect[4] |= 0x02; else memcpy(expect + 8, &c1[i], 8);
+      memcpy(expect + 16, &c2[i], 4);
+      if (memcmp(expect, tuples.data() + (size_t)k * tuple_size, tuple_size) != 0) ++bad;
+      ++k;
+    }
+    CHECK(k == n_tuples && bad == 0 && n_tuples > 0);
+  }
+  // only OPTIONAL slots: the batch counts come from the bitmap
+  std::vector<HdfsParquetScanner::SlotDesc> only_opt = {{1, 8, 4, 0x02}};
+  std::vector<uint8_t> tuples;
+  int64_t n_tuples = -1;
+  CHECK(scanner.AssembleRowsFused(n, tuple_size, tmpl, only_opt, &tuples, &n_tuples) && n_tuples == n);
+  int64_t bad = 0;
+  for (int i = 0; i < n; ++i) {
+    const uint8_t* t = tuples.data() + (size_t)i * tuple_size;
+    int64_t v;
+    memcpy(&v, t + 8, 8);
+    if (c1_null[i] ? !(t[4] & 0x02) : ((t[4] & 0x02) || v != c1[i])) ++bad;
+  }
+  CHECK(bad == 0);
+  CHECK(ips::sticky_status() == IPS_OK);
+}
+
 // ips_eval_program straight through the C-ABI from a plain C++ process: an OR of two conjunctions
 // needs a temporary bitmap next to d_bitmap (stream-ordered allocation inside the call).
 static void TestProgramWithTemporaryBitmap() {
@@ -738,6 +808,7 @@ int main() {
   TestCallPatternLaunchCounts();
   TestTruncatedPages();
   TestColumnChunkStream();
+  TestAssembleRowsFused();
   CHECK(ips::sticky_status() == IPS_OK);
   printf("facade_test: %d checks, %d failed\n", g_checks, g_fail);
   return g_fail ? 1 : 0;
