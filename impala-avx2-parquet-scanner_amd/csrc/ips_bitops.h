@@ -203,7 +203,22 @@ IPS_HD void quads_to_values(uint32_t (&t)[32]) {
 // value at bit position 4*bh + bl from its four quad registers q0..q3 = t[4*bh .. 4*bh+3]
 IPS_HD uint32_t quads_value(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t bl,
                             uint32_t m = 0x11111111u) {
-  return ((q0 >> bl) & m) | (((q1 >> bl) & m) << 1) | (((q2 >> bl) & m) << 2) | (((q3 >> bl) & m) << 3);
+  // three nested bit-selects (v_bfi_b32): every comb position is overwritten by the right term, so
+  // the shifted registers need no masks of their own (10 ops)
+  const uint32_t t0 = q0 >> bl, t1 = (q1 >> bl) << 1, t2 = (q2 >> bl) << 2, t3 = (q3 >> bl) << 3;
+  const uint32_t m1 = m << 1, m2 = m << 2;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (the compiler would turn the portable form back into four ANDs and two ORs)
+  uint32_t x23, x123, r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x23) : "v"(m2), "v"(t2), "v"(t3));
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x123) : "v"(m1), "v"(t1), "v"(x23));
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(t0), "v"(x123));
+#else
+  const uint32_t x23 = (t2 & m2) | (t3 & ~m2);
+  const uint32_t x123 = (t1 & m1) | (x23 & ~m1);
+  const uint32_t r = (t0 & m) | (x123 & ~m);
+#endif
+  return m == 0x11111111u ? r : (r & (m | m1 | m2 | (m << 3)));  // narrow lanes: drop the other lane
 }
 // The same for 9..16-bit columns (R = 16: two values side by side per register): only the stages
 // 8 and 4 of transpose_lanes<16> (48 of 112 ops); the value at bit position 16*q + 4*bh + bl is

@@ -175,8 +175,14 @@ __device__ __forceinline__ void fle_scan_body(
       if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, bm);
     }
     if (MODE == kScanPredicate) {
-      bm = finish_bitmap_dword(pred_from_regs<W>(p, args), tile, lane, n_rows);
-      if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, bm);
+      const uint32_t sel = pred_from_regs<W>(p, args);
+      if ((tile + 1) * kRowsPerTile <= n_rows) {  // wave-uniform: every row of the sub-tile exists
+        bm = bitrev32(sel);
+        IPS_BITMAP_STORE(bitmap32 + d, bm);
+      } else {
+        bm = finish_bitmap_dword(sel, tile, lane, n_rows);
+        if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, bm);
+      }
     } else if (MODE == kScanGivenBitmap) {
       bm = bitrev32(given_cur);  // finish_bitmap_dword reverses back; only the row mask is wanted
       bm = finish_bitmap_dword(bm, tile, lane, n_rows);
@@ -299,7 +305,10 @@ __device__ __forceinline__ void fle_scan_body(
         wave_lds_fence();
         // phase B: 64 entries per round, all lanes busy: entry -> LDS offset of the value -> slot
         int bad = 0;
-        for (uint32_t i = lane; i < count; i += kWave) {
+        const uint32_t rounds = (count + kWave - 1) / kWave;  // wave-uniform trip count
+        for (uint32_t rd = 0; rd < rounds; ++rd) {
+          const uint32_t i = rd * kWave + lane;
+          if (i >= count) continue;  // only lanes of the last round
           const uint32_t e = list[i];
           const uint32_t src = e >> 5, j = e & 31u;
           uint32_t x;
