@@ -362,7 +362,7 @@ class HdfsParquetScanner {
       ips::ok(IPS_ERR_INVALID_ARG, msg);
       return -1;
     };
-    if (!parquet::CodecSupported(codec)) return fail("compression codec not available in this build (UNCOMPRESSED and GZIP are)");
+    if (!parquet::CodecSupported(codec)) return fail("compression codec not supported (UNCOMPRESSED, SNAPPY and GZIP are)");
     if (chunk == nullptr || chunk_len < 0 || num_values < 0) return fail("bad column chunk");
     std::vector<std::unique_ptr<std::vector<uint8_t>>> owned;
     std::vector<uint8_t>* dict_values = nullptr;

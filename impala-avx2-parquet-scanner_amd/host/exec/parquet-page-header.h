@@ -3,8 +3,9 @@
 // (parquet.thrift:163-331) in the compact protocol (what DeserializeThriftMsg(buf, &len, true, ..)
 // parses in BaseColumnReader::ReadDataPage, hdfs-parquet-scanner.cc:762-770, and what
 // thrift_serializer_->Serialize writes in BaseColumnWriter::Flush, hdfs-parquet-table-writer.cc:
-// 519-522, 605-608), plus the page codecs that can be had in this image (UNCOMPRESSED, GZIP via
-// zlib; Snappy is not installed and is refused).
+// 519-522, 605-608), plus the page codecs: UNCOMPRESSED, GZIP (zlib) and SNAPPY (the reference
+// writer's default; util/snappy-codec.h restates the raw block format).  LZO is refused, as the
+// reference's own Parquet scanner does.
 //
 // No thrift dependency: the compact protocol is a handful of varints.  A struct is a sequence of
 // fields, each introduced by one byte (id delta << 4 | type) or, for deltas outside 1..15, by
@@ -17,6 +18,8 @@
 #include <zlib.h>
 
 #include <vector>
+
+#include "../util/snappy-codec.h"
 
 namespace impala {
 namespace parquet {
@@ -259,7 +262,8 @@ inline void SerializePageHeader(const PageHeader& h, std::vector<uint8_t>* out) 
 // ---- page codecs (Codec::ProcessBlock32 of the decompressor_ / compressor_ the reference creates
 // from metadata_->codec, hdfs-parquet-scanner.cc:830-836, 866-876) -------------------------------
 inline bool CodecSupported(int codec) {
-  return codec == CompressionCodec::UNCOMPRESSED || codec == CompressionCodec::GZIP;
+  return codec == CompressionCodec::UNCOMPRESSED || codec == CompressionCodec::GZIP ||
+         codec == CompressionCodec::SNAPPY;
 }
 
 // input -> exactly uncompressed_size bytes of output; false on corrupt data or a size mismatch
@@ -271,7 +275,11 @@ inline bool Decompress(int codec, const uint8_t* in, int64_t in_len, int64_t unc
     out->assign(in, in + in_len);
     return true;
   }
-  if (codec != CompressionCodec::GZIP) return false;  // Snappy / LZO: not available in this image
+  if (codec == CompressionCodec::SNAPPY) {
+    out->assign((size_t)uncompressed_size, 0);
+    return snappy::Uncompress(in, in_len, out->data(), uncompressed_size);
+  }
+  if (codec != CompressionCodec::GZIP) return false;  // LZO
   out->assign((size_t)uncompressed_size + 1, 0);
   z_stream zs;
   memset(&zs, 0, sizeof(zs));
@@ -290,6 +298,7 @@ inline bool Decompress(int codec, const uint8_t* in, int64_t in_len, int64_t unc
 
 inline bool Compress(int codec, const uint8_t* in, int64_t in_len, std::vector<uint8_t>* out) {
   if (codec == CompressionCodec::UNCOMPRESSED) { out->assign(in, in + in_len); return true; }
+  if (codec == CompressionCodec::SNAPPY) { snappy::Compress(in, in_len, out); return true; }
   if (codec != CompressionCodec::GZIP) return false;
   uLongf cap = compressBound((uLong)in_len) + 32;
   out->assign((size_t)cap, 0);

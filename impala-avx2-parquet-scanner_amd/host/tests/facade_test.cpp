@@ -584,7 +584,8 @@ static void TestColumnChunkStream() {
     c1_null[i] = (rnd() % 6) == 0;
     c1[i] = (int64_t)(rnd() % 300) * 1000003ll;
   }
-  for (int codec : {(int)parquet::CompressionCodec::UNCOMPRESSED, (int)parquet::CompressionCodec::GZIP}) {
+  for (int codec : {(int)parquet::CompressionCodec::UNCOMPRESSED, (int)parquet::CompressionCodec::GZIP,
+                    (int)parquet::CompressionCodec::SNAPPY}) {
     ColumnChunkWriter<int32_t> w0(codec, 0, 7000);   // REQUIRED, 5 data pages
     ColumnChunkWriter<int64_t> w1(codec, 1, 11000);  // OPTIONAL, 3 data pages
     for (int i = 0; i < n; ++i) {
@@ -631,7 +632,11 @@ static void TestColumnChunkStream() {
 
     // what ReadDataPage refuses
     HdfsParquetScanner s2;
-    CHECK(s2.AddColumnChunk<int32_t>(chunk0.data(), (int64_t)chunk0.size(), n, parquet::CompressionCodec::SNAPPY, 0, &err) == -1);
+    CHECK(s2.AddColumnChunk<int32_t>(chunk0.data(), (int64_t)chunk0.size(), n, parquet::CompressionCodec::LZO, 0, &err) == -1);
+    if (codec != parquet::CompressionCodec::UNCOMPRESSED)   // the chunk's pages under another codec's name
+      CHECK(s2.AddColumnChunk<int32_t>(chunk0.data(), (int64_t)chunk0.size(), n,
+                                       codec == parquet::CompressionCodec::GZIP ? parquet::CompressionCodec::SNAPPY
+                                                                                : parquet::CompressionCodec::GZIP, 0, &err) == -1);
     CHECK(s2.AddColumnChunk<int32_t>(chunk0.data(), (int64_t)chunk0.size() / 2, n, codec, 0, &err) == -1);   // cut mid-chunk
     CHECK(s2.AddColumnChunk<int32_t>(chunk0.data(), (int64_t)chunk0.size(), n + 5, codec, 0, &err) == -1);  // metadata overstates
     CHECK(s2.AddColumnChunk<int64_t>(chunk0.data(), (int64_t)chunk0.size(), n, codec, 0, &err) == -1);      // wrong slot width

@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <string>
+
 #include "../impala-avx2-parquet-scanner_amd/host/exec/parquet-page-header.h"
 
 using namespace impala::parquet;
@@ -10,7 +12,35 @@ using namespace impala::parquet;
 static int g_fail = 0;
 #define CHECK(c) do { if (!(c)) { ++g_fail; fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #c); } } while (0)
 
-int main() {
+static std::vector<uint8_t> read_file(const char* path) {
+  std::vector<uint8_t> v;
+  FILE* f = fopen(path, "rb");
+  if (!f) return v;
+  uint8_t buf[65536];
+  for (size_t n; (n = fread(buf, 1, sizeof(buf), f)) > 0;) v.insert(v.end(), buf, buf + n);
+  fclose(f);
+  return v;
+}
+
+// file mode for the cross-check against libsnappy in tests/test_host_page_header.py:
+//   host_page_header_test snappy-c <in> <out>  |  snappy-d <in> <out> <uncompressed size>
+static int file_mode(int argc, char** argv) {
+  const std::string mode = argv[1];
+  const std::vector<uint8_t> in = read_file(argv[2]);
+  std::vector<uint8_t> out;
+  bool ok = false;
+  if (mode == "snappy-c" && argc == 4) ok = Compress(CompressionCodec::SNAPPY, in.data(), (int64_t)in.size(), &out);
+  if (mode == "snappy-d" && argc == 5) ok = Decompress(CompressionCodec::SNAPPY, in.data(), (int64_t)in.size(), atoll(argv[4]), &out);
+  if (!ok) return 2;
+  FILE* f = fopen(argv[3], "wb");
+  if (!f) return 3;
+  if (!out.empty()) fwrite(out.data(), 1, out.size(), f);
+  fclose(f);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 4) return file_mode(argc, argv);
   // 1. known bytes.  DATA_PAGE, uncompressed 300, compressed 150, DataPageHeader{1024, FLE_DICTIONARY,
   //    FLE, BIT_PACKED}, written by hand from the compact-protocol rules:
   //    field 1 i32 -> 0x15, zigzag(0) = 0x00; field 2 i32 -> 0x15, zigzag(300) = 600 = 0xD8 0x04;
@@ -103,7 +133,55 @@ int main() {
   CHECK(Decompress(CompressionCodec::GZIP, zl.data(), (int64_t)zn, (int64_t)plain.size(), &back) && back == plain);
   CHECK(Decompress(CompressionCodec::UNCOMPRESSED, plain.data(), 10, 10, &back) && back.size() == 10);
   CHECK(!Decompress(CompressionCodec::UNCOMPRESSED, plain.data(), 10, 11, &back));
-  CHECK(!CodecSupported(CompressionCodec::SNAPPY) && !Decompress(CompressionCodec::SNAPPY, plain.data(), 10, 10, &back));
+  CHECK(!CodecSupported(CompressionCodec::LZO) && !Decompress(CompressionCodec::LZO, plain.data(), 10, 10, &back));
+
+  // 7. Snappy.  Known bytes written by libsnappy (through pyarrow 25.0.0's Codec('snappy')) for
+  //    "hello hello hello hello hello world" x 3: a 6-byte literal, an overlapping copy-2 (offset
+  //    6 < length 24), a literal, two more copy-2s.
+  {
+    const uint8_t gold[] = {0x69, 0x14, 0x68, 0x65, 0x6c, 0x6c, 0x6f, 0x20, 0x5e, 0x06, 0x00, 0x10, 0x77,
+                            0x6f, 0x72, 0x6c, 0x64, 0x5e, 0x1d, 0x00, 0x09, 0x18, 0x9e, 0x23, 0x00};
+    std::string text;
+    for (int i = 0; i < 3; ++i) text += "hello hello hello hello hello world";
+    CHECK(Decompress(CompressionCodec::SNAPPY, gold, sizeof(gold), (int64_t)text.size(), &back));
+    CHECK(std::string(back.begin(), back.end()) == text);
+    CHECK(!Decompress(CompressionCodec::SNAPPY, gold, sizeof(gold), (int64_t)text.size() + 1, &back));
+    CHECK(!Decompress(CompressionCodec::SNAPPY, gold, sizeof(gold) - 2, (int64_t)text.size(), &back));
+    // hand-made streams, one per element kind the compressor above does not emit
+    const uint8_t copy1[] = {0x0C, 0x0C, 'a', 'b', 'c', 'd', 0x11, 0x04};              // literal 4, copy-1 len 8 offset 4
+    CHECK(Decompress(CompressionCodec::SNAPPY, copy1, sizeof(copy1), 12, &back) && std::string(back.begin(), back.end()) == "abcdabcdabcd");
+    const uint8_t copy4[] = {0x08, 0x0C, 'w', 'x', 'y', 'z', 0x0F, 0x04, 0x00, 0x00, 0x00};  // copy-4 len 4 offset 4
+    CHECK(Decompress(CompressionCodec::SNAPPY, copy4, sizeof(copy4), 8, &back) && std::string(back.begin(), back.end()) == "wxyzwxyz");
+    std::vector<uint8_t> longlit = {0x46, 0xF0, 0x45};                                    // 70 bytes: literal with a 1-byte length
+    for (int i = 0; i < 70; ++i) longlit.push_back((uint8_t)i);
+    CHECK(Decompress(CompressionCodec::SNAPPY, longlit.data(), (int64_t)longlit.size(), 70, &back) && back[69] == 69);
+    const uint8_t zero_off[] = {0x08, 0x0C, 'w', 'x', 'y', 'z', 0x0E, 0x00, 0x00};        // offset 0
+    CHECK(!Decompress(CompressionCodec::SNAPPY, zero_off, sizeof(zero_off), 8, &back));
+    const uint8_t far_off[] = {0x08, 0x0C, 'w', 'x', 'y', 'z', 0x0E, 0x05, 0x00};         // offset beyond the output
+    CHECK(!Decompress(CompressionCodec::SNAPPY, far_off, sizeof(far_off), 8, &back));
+    const uint8_t overrun[] = {0x04, 0x0C, 'w', 'x', 'y', 'z', 0x0E, 0x04, 0x00};         // writes past the stated length
+    CHECK(!Decompress(CompressionCodec::SNAPPY, overrun, sizeof(overrun), 4, &back));
+    const uint8_t bad_pre[] = {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0x01};                        // preamble over 32 bits
+    CHECK(!Decompress(CompressionCodec::SNAPPY, bad_pre, sizeof(bad_pre), 8, &back));
+    // round trips: compressible, incompressible, empty, tiny, long runs (copies split in pieces)
+    std::vector<std::vector<uint8_t>> cases;
+    cases.push_back(plain);
+    cases.push_back({});
+    cases.push_back({1, 2, 3});
+    cases.push_back(std::vector<uint8_t>(100000, 7));
+    std::vector<uint8_t> noise(70000);
+    uint64_t x = 88172645463325252ull;
+    for (auto& b : noise) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; b = (uint8_t)(x >> 32); }
+    cases.push_back(noise);
+    std::vector<uint8_t> far(200000);   // repeats further back than 65535: stays literal
+    for (size_t i = 0; i < far.size(); ++i) far[i] = noise[i % 70000];
+    cases.push_back(far);
+    for (const auto& c : cases) {
+      CHECK(Compress(CompressionCodec::SNAPPY, c.data(), (int64_t)c.size(), &comp));
+      CHECK(Decompress(CompressionCodec::SNAPPY, comp.data(), (int64_t)comp.size(), (int64_t)c.size(), &back) && back == c);
+    }
+    CHECK(Compress(CompressionCodec::SNAPPY, cases[3].data(), 100000, &comp) && comp.size() < 6000);
+  }
   CHECK(IsEncodingSupported(Encoding::FLE) && IsEncodingSupported(Encoding::FLE_DICTIONARY) &&
         !IsEncodingSupported(Encoding::DELTA_BINARY_PACKED) && !IsEncodingSupported(Encoding::RLE_DICTIONARY));
 

@@ -145,3 +145,91 @@ def test_more_than_2_31_rows(capi, ips):
     lo = (1 << 31) - 64
     bits = torch.tensor([(int(bm[(lo + i) // 64].item()) >> ((lo + i) % 64)) & 1 for i in range(128)])
     assert torch.equal(bits.bool(), (vals[lo:lo + 128] >= 2).cpu())
+
+
+def _pack(mask):
+    w = mask.view(-1, 64).to(torch.int64)
+    return (w << torch.arange(64, device=w.device, dtype=torch.int64)).sum(dim=1)
+
+
+def test_config2_2p28_rows_int64_between(capi, ips):
+    """configs[2] at full size (2^28 rows): PLAIN int64 and dictionary int64 (D = 4096, w = 12),
+    BETWEEN = And(Ge, Le) at 1 / 10 / 50 / 100 %: every bitmap bit against torch on the raw
+    values, the fused PLAIN scan's selected slots against masked_select."""
+    n = 1 << 28
+    dev = torch.device("cuda")
+    lo32 = capi.synth_u32(0x5EED0003, n, 32).to(torch.int64) & 0xFFFFFFFF
+    plain = (capi.synth_u32(0x5EED1003, n, 8).to(torch.int64) << 32) | lo32      # values mod 2^40
+    del lo32
+    cols = [capi.plain_column(plain, capi.T_INT64)]
+    for sel in (0.01, 0.10, 0.50, 1.0):
+        lo = int((0.5 - sel / 2) * (1 << 40))
+        hi = int((0.5 + sel / 2) * (1 << 40)) - (0 if sel < 1.0 else 1)
+        nodes = [capi.plain_leaf(0, capi.OP_GE, np.int64(lo), capi.T_INT64),
+                 capi.plain_leaf(0, capi.OP_LE, np.int64(hi), capi.T_INT64), capi.and_node()]
+        bm = capi.eval_program(nodes, cols, n)
+        mask = (plain >= lo) & (plain <= hi)
+        assert torch.equal(_pack(mask), bm), sel
+        assert abs(float(mask.sum().item()) / n - sel) < 0.002
+        if sel == 0.10:
+            bm2, bv, cnt = capi.plain_scan(plain, n, capi.T_INT64, capi.OP_GE, np.int64(lo),
+                                           op2=capi.OP_LE, literal2=np.int64(hi))
+            assert torch.equal(bm2, bm)
+            assert torch.equal(capi.batches_compact(bv, cnt, n), torch.masked_select(plain, mask))
+            bv2, cnt2 = capi.plain_select(plain, n, capi.T_INT64, bm)     # streamed batches
+            assert torch.equal(cnt2, cnt)
+            assert torch.equal(capi.batches_compact(bv2, cnt2, n), torch.masked_select(plain, mask))
+            del bv, bv2
+        del mask, bm
+    del plain, cols
+    torch.cuda.empty_cache()
+    D = 4096
+    rng = np.random.default_rng(3)
+    dict_vals = np.sort(rng.choice(np.arange(-2 ** 40, 2 ** 40, 2 ** 18), D, replace=False)).astype(np.int64)
+    codes = ((capi.synth_u32(0x5EED0003, n, 32).to(torch.int64) & 0xFFFFFFFF) % D).to(torch.int32)
+    enc = capi.fle_encode(codes, 12)
+    dd = capi.Dict(dict_vals.view(np.uint8), capi.T_INT64)
+    d_dict = torch.from_numpy(dict_vals).to(dev)
+    for sel in (0.01, 0.10, 0.50, 1.0):
+        lo = dict_vals[int((0.5 - sel / 2) * (D - 1))]
+        hi = dict_vals[int((0.5 + sel / 2) * (D - 1))]
+        a = dd.pred(enc, n, 12, capi.OP_GE, lo)
+        b = dd.pred(enc, n, 12, capi.OP_LE, hi)
+        got = capi.bitmap_and(a.clone(), b, n)
+        lo_c, hi_c = int(np.searchsorted(dict_vals, lo)), int(np.searchsorted(dict_vals, hi, side="right"))
+        mask = (codes >= lo_c) & (codes < hi_c)
+        assert torch.equal(_pack(mask), got), sel
+        if sel == 0.10:   # the gather of the selected rows' dictionary values
+            bv, cnt = dd.select(enc, n, 12, got)
+            assert torch.equal(capi.batches_compact(bv, cnt, n), d_dict[torch.masked_select(codes, mask).to(torch.int64)])
+            del bv
+        del a, b, got, mask
+    dd.close()
+
+
+def test_config3_2p28_rows_dictionary_in_list(capi, ips):
+    """configs[3] at full size (2^28 rows): dictionary int32, D in {256, 4096, 40000}, IN lists of
+    4 and 16 literals (half absent), fused scan + gather: bitmap bits and gathered values against
+    torch on the raw codes."""
+    n = 1 << 28
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(4)
+    for D in (256, 4096, 40000):
+        bw = capi.dict_bit_width(D)
+        dict_vals = np.sort(rng.choice(np.arange(-2 ** 30, 2 ** 30, 7), D, replace=False)).astype(np.int32)
+        codes = ((capi.synth_u32(ips.synth.SEED_DICT, n, 32).to(torch.int64) & 0xFFFFFFFF) % D).to(torch.int32)
+        enc = capi.fle_encode(codes, bw)
+        dd = capi.Dict(dict_vals.view(np.uint8), capi.T_INT32)
+        d_dict = torch.from_numpy(dict_vals).to(dev)
+        for K in (4, 16):
+            present = rng.choice(D, K // 2, replace=False)
+            lits = np.concatenate([dict_vals[present], dict_vals[present] + 1]).astype(np.int32)
+            bitmap, bvals, counts = dd.scan(enc, n, bw, capi.OP_IN, lits)
+            mask = torch.isin(codes, torch.tensor(np.sort(present), device=dev, dtype=torch.int32))
+            assert torch.equal(_pack(mask), bitmap), (D, K)
+            assert torch.equal(capi.batches_compact(bvals, counts, n),
+                               d_dict[torch.masked_select(codes, mask).to(torch.int64)]), (D, K)
+            del bitmap, bvals, counts, mask
+        dd.close()
+        del codes, enc
+        torch.cuda.empty_cache()
