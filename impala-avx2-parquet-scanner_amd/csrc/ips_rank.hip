@@ -9,20 +9,34 @@
 //      (its row count is never needed on the host: the buffer's size bounds it),
 //   2. rank_tile_counts_kernel counts the non-NULL rows of every 262144-row tile straight from the
 //      definition levels (width 1, max_def 1: the level words ARE the NOT-NULL bits, MSB first),
-//   3. expand_kernel gives every output word its rank (tile base = sum of the tile counts before
-//      it, re-summed per workgroup from L2; inside the tile a wave-level DPP scan), fetches the
-//      64-bit window of data bits at that rank and deposits it into the NOT-NULL positions
-//      (four mask bits at a time through a 256-entry table in LDS), optionally AND-ing / OR-ing
-//      into an existing bitmap (ips_eval_program's combine modes).
+//   3. expand_kernel (workgroups of a quarter tile) gives every output word its rank (base = sum
+//      of the tile counts before its tile, re-summed per workgroup from L2, plus the counts of the
+//      tile's earlier waves; inside the workgroup a wave-level DPP scan), fetches the window of
+//      data bits at that rank and deposits it into the NOT-NULL positions (four mask bits at a
+//      time through a 256-entry table in LDS), optionally AND-ing / OR-ing into an existing
+//      bitmap (ips_eval_program's combine modes).
 // HBM traffic: def levels twice (n/8 bytes each), the data bitmap once in, the result once out.
 #include "ips_host.h"
 
 namespace ips {
 
 constexpr int kRankThreads = 256;
+constexpr int kRankWaves = kRankThreads / kWave;
 constexpr int kRankRounds = 8;                                   // 16-byte loads per lane
 constexpr int kRankWordsPerWave = kWave * 2 * kRankRounds;        // 1024 words = 65536 rows
-constexpr int kRankWordsPerTile = kRankWordsPerWave * (kRankThreads / kWave);  // 4096 words
+constexpr int kRankWordsPerTile = kRankWordsPerWave * kRankWaves;  // 4096 words
+// expand_kernel works on quarter tiles: a workgroup takes the 1024 words one counting WAVE covered
+// (4 waves x 2 rounds), so the grid has 4x the blocks of the counting pass -- several generations
+// of workgroups per CU, whose load / deposit / store phases overlap (with one generation of
+// 4096-word blocks every wave of the chip was in the same phase: 38 -> 34 us for 2^28 rows)
+#ifndef IPS_EXP_ROUNDS
+#define IPS_EXP_ROUNDS 2
+#endif
+constexpr int kExpRounds = IPS_EXP_ROUNDS;
+constexpr int kExpWordsPerWave = kWave * 2 * kExpRounds;          // 256 words
+constexpr int kExpWordsPerBlock = kExpWordsPerWave * kRankWaves;   // 1024 words
+constexpr int kExpBlocksPerTile = kRankWordsPerTile / kExpWordsPerBlock;
+static_assert(kExpBlocksPerTile >= 1 && kRankWaves % kExpBlocksPerTile == 0, "an expand block is whole counting waves");
 
 typedef unsigned long long u64;
 
@@ -40,14 +54,14 @@ __device__ __forceinline__ u64 root_mask(u64 w, int64_t word, int64_t n_rows) {
   return w;
 }
 
-// the wave's 8 x 2 root words of tile 'tile' (word index of (round r, lane, e) =
+// the wave's R x 2 root words from word 'first' on (word index of (round r, lane, e) =
 // first + r * 128 + 2 * lane + e), masked; words beyond n_words are zero
-template <int ROOT>
+template <int ROOT, int R>
 __device__ __forceinline__ void load_root(const u64* __restrict__ root, int64_t first,
                                           int64_t n_words, int64_t n_rows, int lane,
-                                          u64 (&m)[kRankRounds][2]) {
+                                          u64 (&m)[R][2]) {
 #pragma unroll
-  for (int r = 0; r < kRankRounds; ++r) {
+  for (int r = 0; r < R; ++r) {
     const int64_t w0 = first + r * 128 + 2 * lane;
     u64 a = 0, b = 0;
     if (w0 + 1 < n_words) {
@@ -62,10 +76,29 @@ __device__ __forceinline__ void load_root(const u64* __restrict__ root, int64_t 
   }
 }
 
+// the same for a wave whose R x 128 words are all whole words of rows: no bounds, no row masks
+template <int ROOT, int R>
+__device__ __forceinline__ void load_root_whole(const u64* __restrict__ root, int64_t first, int lane,
+                                                u64 (&m)[R][2]) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const u32x4 t = stream_load<true>(reinterpret_cast<const u32x4*>(root + first + r * 128 + 2 * lane));
+    if (ROOT == kRootLevels1) {
+      m[r][0] = ((u64)__builtin_bitreverse32(t.x) << 32) | __builtin_bitreverse32(t.y);
+      m[r][1] = ((u64)__builtin_bitreverse32(t.z) << 32) | __builtin_bitreverse32(t.w);
+    } else {
+      m[r][0] = ((u64)t.y << 32) | t.x;
+      m[r][1] = ((u64)t.w << 32) | t.z;
+    }
+  }
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
   return __builtin_amdgcn_readlane(wave_inclusive_scan(x), 63);
 }
 
+// tile_counts[t] = set root bits of tile t; tile_counts[tiles + 4 t + w] = those of its wave w (the
+// quarter tiles expand_kernel works on).
 // ZERO: also clears the words of 'zero_out' that belong to the tile (the compress output must start
 // as zeros where two waves share a word; clearing it here saves a memset launch)
 template <int ROOT, bool ZERO>
@@ -78,7 +111,7 @@ __global__ __launch_bounds__(kRankThreads) void rank_tile_counts_kernel(
   const int64_t n_words = (n_rows + 63) / 64;
   const int64_t first = (int64_t)blockIdx.x * kRankWordsPerTile + wave * kRankWordsPerWave;
   u64 m[kRankRounds][2];
-  load_root<ROOT>(root, first, n_words, n_rows, lane, m);
+  load_root<ROOT, kRankRounds>(root, first, n_words, n_rows, lane, m);
   if (ZERO) {
 #pragma unroll
     for (int r = 0; r < kRankRounds; ++r) {
@@ -95,7 +128,10 @@ __global__ __launch_bounds__(kRankThreads) void rank_tile_counts_kernel(
 #pragma unroll
   for (int r = 0; r < kRankRounds; ++r) c += __builtin_popcountll(m[r][0]) + __builtin_popcountll(m[r][1]);
   const uint32_t tot = wave_sum(c);
-  if (lane == 0) wave_tot[wave] = tot;
+  if (lane == 0) {
+    wave_tot[wave] = tot;
+    tile_counts[gridDim.x + blockIdx.x * kRankWaves + wave] = tot;
+  }
   __syncthreads();
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
 }
@@ -103,68 +139,128 @@ __global__ __launch_bounds__(kRankThreads) void rank_tile_counts_kernel(
 // pdep of the low popcount(mask) bits of src into the set positions of mask, four mask bits at a
 // time: table[mask4 << 4 | src4].  Per nibble: two bit-field extracts (the second at the running
 // rank of the nibble inside its 32-bit half), one table read, one shift-or, one popcount-add.
-__device__ __forceinline__ u64 deposit64(u64 src, u64 mask, const uint8_t* __restrict__ lut) {
-  uint32_t out[2];
+__device__ __forceinline__ uint32_t deposit32(uint32_t sh, uint32_t mh, const uint8_t* __restrict__ lut) {
+  uint32_t o = 0, rank = 0;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const uint32_t mh = (uint32_t)(mask >> (32 * h));
-    const uint32_t sh = h == 0 ? (uint32_t)src : (uint32_t)(src >> __builtin_popcount((uint32_t)mask));
-    uint32_t o = 0, rank = 0;
-#pragma unroll
-    for (int n = 0; n < 8; ++n) {
-      const uint32_t m4 = (mh >> (4 * n)) & 15u;
-      const uint32_t s4 = (sh >> rank) & 15u;  // rank <= 28
-      o |= (uint32_t)lut[(m4 << 4) | s4] << (4 * n);
-      rank += (uint32_t)__builtin_popcount(m4);
-    }
-    out[h] = o;
+  for (int n = 0; n < 8; ++n) {
+    const uint32_t m4 = (mh >> (4 * n)) & 15u;
+    const uint32_t s4 = (sh >> rank) & 15u;  // rank <= 28
+    o |= (uint32_t)lut[(m4 << 4) | s4] << (4 * n);
+    rank += (uint32_t)__builtin_popcount(m4);
   }
-  return (u64)out[0] | ((u64)out[1] << 32);
+  return o;
 }
 
-__device__ __forceinline__ void deposit_lut_init(uint8_t* lut) {  // 256 threads: one entry each
-  const uint32_t m = threadIdx.x >> 4, v = threadIdx.x & 15u;
-  uint32_t d = 0, j = 0;
-#pragma unroll
-  for (uint32_t bit = 0; bit < 4; ++bit) {
-    if (m & (1u << bit)) {
-      if (v & (1u << j)) d |= 1u << bit;
-      ++j;
-    }
-  }
-  lut[threadIdx.x] = (uint8_t)d;
+__device__ __forceinline__ u64 deposit64(u64 src, u64 mask, const uint8_t* __restrict__ lut) {
+  const uint32_t lo = deposit32((uint32_t)src, (uint32_t)mask, lut);
+  const uint32_t hi = deposit32((uint32_t)(src >> __builtin_popcount((uint32_t)mask)), (uint32_t)(mask >> 32), lut);
+  return (u64)lo | ((u64)hi << 32);
 }
+
+// the 256-entry tables, built at compile time and copied from the code object's constant data
+// into LDS by each workgroup (one byte per thread)
+struct NibbleLut { uint8_t v[256]; };
+constexpr NibbleLut make_deposit_lut() {
+  NibbleLut t{};
+  for (uint32_t i = 0; i < 256; ++i) {
+    const uint32_t m = i >> 4, v = i & 15u;
+    uint32_t d = 0, j = 0;
+    for (uint32_t bit = 0; bit < 4; ++bit) {
+      if (m & (1u << bit)) {
+        if (v & (1u << j)) d |= 1u << bit;
+        ++j;
+      }
+    }
+    t.v[i] = (uint8_t)d;
+  }
+  return t;
+}
+constexpr NibbleLut make_extract_lut() {
+  NibbleLut t{};
+  for (uint32_t i = 0; i < 256; ++i) {
+    const uint32_t m = i >> 4, v = i & 15u;
+    uint32_t e = 0, j = 0;
+    for (uint32_t bit = 0; bit < 4; ++bit) {
+      if (m & (1u << bit)) {
+        if (v & (1u << bit)) e |= 1u << j;
+        ++j;
+      }
+    }
+    t.v[i] = (uint8_t)e;
+  }
+  return t;
+}
+__device__ const NibbleLut kDepositLut = make_deposit_lut();
+__device__ const NibbleLut kExtractLut = make_extract_lut();
+
+__device__ __forceinline__ void deposit_lut_init(uint8_t* lut) { lut[threadIdx.x] = kDepositLut.v[threadIdx.x]; }
 
 // out word i = deposit(sub bits [rank(i), rank(i) + popcount(root_i)), root_i), where rank(i) is the
 // number of set root bits before word i.  Data bits at or beyond n_sub_bits read as 0 (a page
-// whose NOT-NULL count exceeds its data rows selects nothing there).  combine: 0 store, 1 and,
+// whose NOT-NULL count exceeds its data rows selects nothing there).  COMBINE: 0 store, 1 and,
 // 2 or into out.
-template <int ROOT>
+//
+// A wave whose words are all whole and whose data bits (plus the 96 bits a window load may touch)
+// all exist takes the fast path: 32-bit offsets relative to the wave's base, the data window of a
+// word = three dwords at dword granularity (issued for the wave's four words before the first
+// deposit) funnel-shifted with v_alignbit, no per-word bounds arithmetic.  The last waves of a
+// launch take the general path.  (SQ counters, 2^28 rows: 169 -> 118 VALU per word.)
+struct __attribute__((packed, aligned(4))) Window3 { uint32_t d0, d1, d2; };
+
+template <int COMBINE>
+__device__ __forceinline__ void expand_store(u64* __restrict__ out, int64_t w0, int64_t n_words, u64 (&res)[2]) {
+  if (w0 + 1 < n_words) {
+    u32x4* dst = reinterpret_cast<u32x4*>(out + w0);
+    if (COMBINE) {
+      const u32x4 old = *dst;
+      const u64 o0 = ((u64)old.y << 32) | old.x, o1 = ((u64)old.w << 32) | old.z;
+      res[0] = COMBINE == 1 ? (res[0] & o0) : (res[0] | o0);
+      res[1] = COMBINE == 1 ? (res[1] & o1) : (res[1] | o1);
+    }
+    const u32x4 t = {(uint32_t)res[0], (uint32_t)(res[0] >> 32), (uint32_t)res[1], (uint32_t)(res[1] >> 32)};
+    IPS_STREAM_STORE16(dst, t);
+  } else {
+    if (COMBINE) res[0] = COMBINE == 1 ? (res[0] & out[w0]) : (res[0] | out[w0]);
+    out[w0] = res[0];
+  }
+}
+
+template <int ROOT, int COMBINE>
 __global__ __launch_bounds__(kRankThreads) void expand_kernel(
     const u64* __restrict__ root, const u64* __restrict__ sub, int64_t n_rows, int64_t n_sub_bits,
-    const uint32_t* __restrict__ tile_counts, u64* __restrict__ out, int combine) {
+    const uint32_t* __restrict__ tile_counts, int64_t tiles, u64* __restrict__ out) {
   __shared__ uint8_t lut[256];
-  __shared__ u64 part[kRankThreads / kWave];
-  __shared__ uint32_t wave_tot[kRankThreads / kWave];
+  __shared__ u64 part[kRankWaves];
+  __shared__ uint32_t wave_tot[kRankWaves];
   const int lane = lane_id();
   const int wave = wave_id();
   const int64_t n_words = (n_rows + 63) / 64;
   const int64_t n_sub_words = (n_sub_bits + 63) / 64;
   deposit_lut_init(lut);
-  // tile base: the non-NULL rows of all tiles before this one
-  u64 before = 0;
-  for (int64_t i = threadIdx.x; i < (int64_t)blockIdx.x; i += kRankThreads) before += tile_counts[i];
-  for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
-  if (lane == 0) part[wave] = before;
+  const int64_t first = (int64_t)blockIdx.x * kExpWordsPerBlock + wave * kExpWordsPerWave;
+  const bool whole = (first + kExpWordsPerWave) * 64 <= n_rows;  // wave-uniform
+  u64 m[kExpRounds][2];
+  if (whole) load_root_whole<ROOT, kExpRounds>(root, first, lane, m);
+  else load_root<ROOT, kExpRounds>(root, first, n_words, n_rows, lane, m);
+  // block base: the non-NULL rows of all tiles before this block's tile and of the parts of the
+  // tile before this block (the counts of the tile's waves).  A thread's partial sum fits 32 bits
+  // (<= 2^18 per tile, n_rows < 2^40: launch_expand checks); the wave total is formed from two
+  // 16-bit halves so that no 32-bit scan can overflow.
+  const int64_t tile = (int64_t)blockIdx.x / kExpBlocksPerTile;
+  const int part_waves = (int)(blockIdx.x % kExpBlocksPerTile) * (kRankWaves / kExpBlocksPerTile);
+  uint32_t before = 0;
+  for (int64_t i = threadIdx.x; i < tile; i += kRankThreads) before += tile_counts[i];
+  if ((int)threadIdx.x < part_waves) before += tile_counts[tiles + tile * kRankWaves + threadIdx.x];
+  {
+    const uint32_t lo = wave_sum(before & 0xFFFFu), hi = wave_sum(before >> 16);
+    if (lane == 0) part[wave] = (u64)lo + ((u64)hi << 16);
+  }
 
-  const int64_t first = (int64_t)blockIdx.x * kRankWordsPerTile + wave * kRankWordsPerWave;
-  u64 m[kRankRounds][2];
-  load_root<ROOT>(root, first, n_words, n_rows, lane, m);
   // exclusive rank of every pair of words inside the wave: per round a DPP scan over the lanes
-  uint32_t excl[kRankRounds];
+  uint32_t excl[kExpRounds];
   uint32_t run = 0;
 #pragma unroll
-  for (int r = 0; r < kRankRounds; ++r) {
+  for (int r = 0; r < kExpRounds; ++r) {
     const uint32_t c = (uint32_t)(__builtin_popcountll(m[r][0]) + __builtin_popcountll(m[r][1]));
     const uint32_t incl = wave_inclusive_scan(c);
     excl[r] = run + incl - c;
@@ -175,8 +271,41 @@ __global__ __launch_bounds__(kRankThreads) void expand_kernel(
   u64 base = part[0] + part[1] + part[2] + part[3];
   for (int w = 0; w < wave; ++w) base += wave_tot[w];
 
+  const bool fast = whole && base + run + 128 <= (u64)n_sub_bits;
+  if (fast) {  // wave-uniform
+    const uint32_t* __restrict__ sp = reinterpret_cast<const uint32_t*>(sub + (base >> 6));
+    const uint32_t lead = (uint32_t)(base & 63);
+    Window3 win[kExpRounds][2];
+    uint32_t sh[kExpRounds][2];
 #pragma unroll
-  for (int r = 0; r < kRankRounds; ++r) {
+    for (int r = 0; r < kExpRounds; ++r) {
+      uint32_t rel = lead + excl[r];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        win[r][e] = *reinterpret_cast<const Window3*>(sp + (rel >> 5));
+        sh[r][e] = rel & 31u;
+        rel += (uint32_t)__builtin_popcountll(m[r][e]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kExpRounds; ++r) {
+      u64 res[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const uint32_t mlo = (uint32_t)m[r][e], mhi = (uint32_t)(m[r][e] >> 32);
+        const uint32_t lo = __builtin_amdgcn_alignbit(win[r][e].d1, win[r][e].d0, sh[r][e]);
+        const uint32_t hi = __builtin_amdgcn_alignbit(win[r][e].d2, win[r][e].d1, sh[r][e]);
+        const uint32_t pcl = (uint32_t)__builtin_popcount(mlo);
+        const uint32_t src_hi = pcl == 32u ? hi : __builtin_amdgcn_alignbit(hi, lo, pcl);
+        res[e] = (u64)deposit32(lo, mlo, lut) | ((u64)deposit32(src_hi, mhi, lut) << 32);
+      }
+      expand_store<COMBINE>(out, first + r * 128 + 2 * lane, n_words, res);
+    }
+    return;
+  }
+
+#pragma unroll
+  for (int r = 0; r < kExpRounds; ++r) {
     const int64_t w0 = first + r * 128 + 2 * lane;
     if (w0 >= n_words) continue;
     u64 res[2];
@@ -199,20 +328,7 @@ __global__ __launch_bounds__(kRankThreads) void expand_kernel(
       res[e] = deposit64(bits, mk, lut);
       off += pc;
     }
-    if (w0 + 1 < n_words) {
-      u32x4* dst = reinterpret_cast<u32x4*>(out + w0);
-      if (combine) {
-        const u32x4 old = *dst;
-        const u64 o0 = ((u64)old.y << 32) | old.x, o1 = ((u64)old.w << 32) | old.z;
-        res[0] = combine == 1 ? (res[0] & o0) : (res[0] | o0);
-        res[1] = combine == 1 ? (res[1] & o1) : (res[1] | o1);
-      }
-      const u32x4 t = {(uint32_t)res[0], (uint32_t)(res[0] >> 32), (uint32_t)res[1], (uint32_t)(res[1] >> 32)};
-      IPS_STREAM_STORE16(dst, t);
-    } else {
-      if (combine) res[0] = combine == 1 ? (res[0] & out[w0]) : (res[0] | out[w0]);
-      out[w0] = res[0];
-    }
+    expand_store<COMBINE>(out, w0, n_words, res);
   }
 }
 
@@ -221,8 +337,10 @@ int64_t rank_tiles(int64_t n_rows) {
   return (n_words + kRankWordsPerTile - 1) / kRankWordsPerTile;
 }
 
-// workspace: tile counts only
-size_t rank_workspace_bytes(int64_t n_rows) { return ((size_t)rank_tiles(n_rows) * 4 + 255) & ~(size_t)255; }
+// workspace: tile counts + the counts of each tile's four waves
+size_t rank_workspace_bytes(int64_t n_rows) {
+  return ((size_t)rank_tiles(n_rows) * (1 + kRankWaves) * 4 + 255) & ~(size_t)255;
+}
 
 // root_kind: kRootBitmap / kRootLevels1.  tile_counts: rank_tiles(n_rows) uint32 (workspace).
 ips_status launch_rank_tile_counts(int root_kind, const uint64_t* root, int64_t n_rows,
@@ -243,13 +361,19 @@ ips_status launch_expand(int root_kind, const uint64_t* root, const uint64_t* su
                          int combine, hipStream_t s) {
   const int64_t tiles = rank_tiles(n_rows);
   if (tiles <= 0) return IPS_OK;
+  IPS_REQUIRE(n_rows < (1ll << 40), "expand: %lld rows (the rank kernels take fewer than 2^40)", (long long)n_rows);
   const u64* r = reinterpret_cast<const u64*>(root);
   const u64* sb = reinterpret_cast<const u64*>(sub);
   u64* o = reinterpret_cast<u64*>(out);
-  if (root_kind == kRootLevels1)
-    hipLaunchKernelGGL(expand_kernel<kRootLevels1>, dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, sb, n_rows, n_sub_bits, tile_counts, o, combine);
-  else
-    hipLaunchKernelGGL(expand_kernel<kRootBitmap>, dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, sb, n_rows, n_sub_bits, tile_counts, o, combine);
+  const int64_t n_words = (n_rows + 63) / 64;
+  const dim3 grid((unsigned)((n_words + kExpWordsPerBlock - 1) / kExpWordsPerBlock));
+#define IPS_EXPAND(R, C) hipLaunchKernelGGL((expand_kernel<R, C>), grid, dim3(kRankThreads), 0, s, r, sb, n_rows, n_sub_bits, tile_counts, tiles, o)
+  if (root_kind == kRootLevels1) {
+    if (combine == 0) IPS_EXPAND(kRootLevels1, 0); else if (combine == 1) IPS_EXPAND(kRootLevels1, 1); else IPS_EXPAND(kRootLevels1, 2);
+  } else {
+    if (combine == 0) IPS_EXPAND(kRootBitmap, 0); else if (combine == 1) IPS_EXPAND(kRootBitmap, 1); else IPS_EXPAND(kRootBitmap, 2);
+  }
+#undef IPS_EXPAND
   IPS_HIP_TRY(hipGetLastError());
   return IPS_OK;
 }
@@ -271,18 +395,7 @@ ips_status launch_bitmap_expand(const uint64_t* root, const uint64_t* sub, int64
 // pieces of neighbouring lanes share words) and leaves as whole words; only the first and the last
 // word of a wave's segment can be shared with another wave and go out as global atomics (the
 // output was cleared by the counting pass).  Round 1 issued two global atomics per input word.
-__device__ __forceinline__ void extract_lut_init(uint8_t* lut) {  // 256 threads: one entry each
-  const uint32_t m = threadIdx.x >> 4, v = threadIdx.x & 15u;
-  uint32_t e = 0, j = 0;
-#pragma unroll
-  for (uint32_t bit = 0; bit < 4; ++bit) {
-    if (m & (1u << bit)) {
-      if (v & (1u << bit)) e |= 1u << j;
-      ++j;
-    }
-  }
-  lut[threadIdx.x] = (uint8_t)e;
-}
+__device__ __forceinline__ void extract_lut_init(uint8_t* lut) { lut[threadIdx.x] = kExtractLut.v[threadIdx.x]; }
 
 __device__ __forceinline__ u64 extract64(u64 src, u64 mask, const uint8_t* __restrict__ lut) {
   u64 out = 0;
@@ -327,8 +440,8 @@ __global__ __launch_bounds__(kRankThreads) void compress_kernel(
 
   const int64_t first = (int64_t)blockIdx.x * kRankWordsPerTile + wave * kRankWordsPerWave;
   u64 m[kRankRounds][2], sv[kRankRounds][2];
-  load_root<MASK>(mask, first, n_words, n_rows, lane, m);
-  load_root<SRC>(src, first, n_words, n_rows, lane, sv);
+  load_root<MASK, kRankRounds>(mask, first, n_words, n_rows, lane, m);
+  load_root<SRC, kRankRounds>(src, first, n_words, n_rows, lane, sv);
   uint32_t excl[kRankRounds];
   uint32_t run = 0;
 #pragma unroll
