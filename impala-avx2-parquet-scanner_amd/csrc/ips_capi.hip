@@ -358,14 +358,19 @@ static ips_status nullable_leaf(const void* d_def_levels, int def_bit_width, int
   int root_kind = 0;
   const uint64_t* root = nullptr;
   ips_status st = nullable_prepare_root(d_def_levels, def_bit_width, max_def_level, n_rows, ws,
-                                        &root_kind, &root, s);
+                                        &root_kind, &root, s, /*count_tiles=*/false);
   if (st != IPS_OK) return st;
   int64_t n_sub = n_data_rows < n_rows ? n_data_rows : n_rows;  // a page holds no more data rows than rows
-  if (kind == kAllTrue) {
-    n_sub = n_rows;
-    st = launch_bitmap_fill(ws.sub, n_rows, 1, s);
-  } else if (n_sub > 0) {
-    st = launch_fle_pred(bit_width, reinterpret_cast<const uint64_t*>(d_data_enc), n_sub, args,
+  if (kind == kAllTrue || n_sub <= 0) {
+    st = launch_rank_tile_counts(root_kind, root, n_rows, ws.tile_counts, s);
+    if (st == IPS_OK && kind == kAllTrue) {
+      n_sub = n_rows;
+      st = launch_bitmap_fill(ws.sub, n_rows, 1, s);
+    }
+  } else {
+    PredArgs with_counts = args;  // the tile counts ride on the data predicate's launch
+    attach_rank_counts(&with_counts, root_kind, root, n_rows, ws.tile_counts);
+    st = launch_fle_pred(bit_width, reinterpret_cast<const uint64_t*>(d_data_enc), n_sub, with_counts,
                          reinterpret_cast<uint32_t*>(ws.sub), s);
   }
   if (st != IPS_OK) return st;

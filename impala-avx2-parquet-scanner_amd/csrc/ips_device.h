@@ -38,6 +38,14 @@ struct PredArgs {
   int32_t join;      // 0: single predicate; 1 / 2: result = pred(op, consts[0]) AND / OR
   int32_t op2;       //    pred(op2, const2), both evaluated in ONE pass over the planes
   uint32_t const2;   //    (BETWEEN = Ge AND Le arrives this way)
+  // tile counts of a NOT-NULL root that ride on this launch (nullable leaf, ips_rank_device.h):
+  // workgroups [0, aux_blocks) count tile blockIdx.x of aux_root and exit, the predicate runs on
+  // the workgroups behind them.  aux_blocks = 0: none.
+  int32_t aux_blocks;
+  int32_t aux_kind;  // RootKind
+  const void* aux_root;
+  int64_t aux_rows;
+  uint32_t* aux_counts;
   uint32_t consts[256];
 };
 

@@ -6,6 +6,7 @@
 // selected row (scan/select) or out_width bytes per row (decode).
 #pragma once
 #include "ips_device.h"
+#include "ips_rank_device.h"
 
 // nt loads in decode / encode pay once their output streams are nt stores as well (-3...-4 %);
 // with plain stores they measured 4 % slower.
@@ -461,15 +462,19 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_w_ker
     uint32_t* __restrict__ bitmap32) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * plane_tile_bytes(W) / 4];
   constexpr int L = (16 * W + kWave - 1) / kWave;
+  if ((int)blockIdx.x < args.aux_blocks) {  // counting workgroups of a nullable leaf
+    rank_aux_counts(args);
+    return;
+  }
   const int lane = lane_id();
   const int wave = wave_id();
   uint32_t* lds32 = lds_all + wave * (plane_tile_bytes(W) / 4);
 
   const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   const int64_t total_words = ((n_rows + 63) / 64) * W;
-  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t stride = (int64_t)((int)gridDim.x - args.aux_blocks) * kWavesPerBlock;
   const int64_t bm_dwords = bitmap_dwords(n_rows);
-  int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  int64_t tile = (int64_t)((int)blockIdx.x - args.aux_blocks) * kWavesPerBlock + wave;
   constexpr bool kInTable = KIND == kPredInTable && InTable<W>::kUse;
   __shared__ uint32_t in_table[kInTable ? InTable<W>::kDwords : 1];
   if constexpr (kInTable) in_table_build<W>(in_table, args);
@@ -532,12 +537,16 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_ear
     uint32_t* __restrict__ bitmap32) {
   static_assert(W == 32, "two 128-byte lines per block");
   __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * plane_tile_bytes(W) / 4];
+  if ((int)blockIdx.x < args.aux_blocks) {  // counting workgroups of a nullable leaf
+    rank_aux_counts(args);
+    return;
+  }
   const int lane = lane_id();
   const int wave = wave_id();
   uint32_t* lds32 = lds_all + wave * (plane_tile_bytes(W) / 4);
   const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   const int64_t total_words = ((n_rows + 63) / 64) * W;
-  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t stride = (int64_t)((int)gridDim.x - args.aux_blocks) * kWavesPerBlock;
   const int64_t bm_dwords = bitmap_dwords(n_rows);
   const uint32_t c = args.consts[0];
   const uint32_t c2 = args.const2;
@@ -585,7 +594,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_ear
     return borrow_select(b, op);
   };
 
-  int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  int64_t tile = (int64_t)((int)blockIdx.x - args.aux_blocks) * kWavesPerBlock + wave;
   bool with_low = false;  // wave-uniform: the previous sub-tile needed the low planes
   u32x4 rh[4], rl[4];
   if (tile < tiles) load_half(tile, 1, rh);

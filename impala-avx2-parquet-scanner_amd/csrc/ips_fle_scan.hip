@@ -123,7 +123,7 @@ static ips_status launch_pred_wk(const uint64_t* enc, int64_t n_rows, const Pred
   const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   int grid = grid_for_tiles(reinterpret_cast<const void*>(kern), tiles);
   if (grid <= 0) return IPS_ERR_HIP;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, s, enc, n_rows, args, bitmap32);
+  hipLaunchKernelGGL(kern, dim3(grid + args.aux_blocks), dim3(kThreads), 0, s, enc, n_rows, args, bitmap32);
   IPS_HIP_TRY(hipGetLastError());
   return IPS_OK;
 }
@@ -138,7 +138,7 @@ static ips_status launch_pred_w(const uint64_t* enc, int64_t n_rows, const PredA
       auto kern = args.join != 0 ? fle_pred32_early_kernel<32, true> : fle_pred32_early_kernel<32, false>;
       int grid = grid_for_tiles(reinterpret_cast<const void*>(kern), tiles);
       if (grid <= 0) return IPS_ERR_HIP;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, s, enc, n_rows, args, bitmap32);
+      hipLaunchKernelGGL(kern, dim3(grid + args.aux_blocks), dim3(kThreads), 0, s, enc, n_rows, args, bitmap32);
       IPS_HIP_TRY(hipGetLastError());
       return IPS_OK;
     }

@@ -86,9 +86,13 @@ struct NullableWs {
 size_t nullable_workspace_bytes(int64_t n_rows);
 NullableWs nullable_workspace(void* d_workspace, int64_t n_rows);
 // NOT-NULL root of an OPTIONAL column: returns the root kind and pointer after (if the levels are
-// wider than a bit) evaluating def == max_def into ws.nonnull; then counts the tiles.
+// wider than a bit) evaluating def == max_def into ws.nonnull; then counts the tiles, unless the
+// caller lets the counts ride on its next predicate launch (count_tiles = false, then
+// attach_rank_counts on that launch's arguments).
 ips_status nullable_prepare_root(const void* d_def_levels, int def_bit_width, int max_def_level,
                                  int64_t n_rows, const NullableWs& ws, int* root_kind,
-                                 const uint64_t** root, hipStream_t s);
+                                 const uint64_t** root, hipStream_t s, bool count_tiles = true);
+void attach_rank_counts(PredArgs* args, int root_kind, const uint64_t* root, int64_t n_rows,
+                        uint32_t* tile_counts);
 
 }  // namespace ips

@@ -466,7 +466,8 @@ struct ChainItem {
 struct NullableCol {
   int root_kind = 0;
   const uint64_t* root = nullptr;
-  const uint32_t* tile_counts = nullptr;
+  uint32_t* tile_counts = nullptr;
+  bool counted = false;  // the tile counts ride on the column's first data-predicate launch
 };
 struct NullableCtx {
   NullableCol col[IPS_PROGRAM_MAX_COLS];
@@ -474,7 +475,7 @@ struct NullableCtx {
 };
 
 ips_status emit_item(const ChainItem& it, int combine, const ips_column* cols, int64_t n_rows,
-                     uint64_t* d_bitmap, const NullableCtx& nctx, hipStream_t s) {
+                     uint64_t* d_bitmap, NullableCtx& nctx, hipStream_t s) {
   const ips_column& c = cols[it.a->column];
   if (c.encoding == IPS_COL_FLE) {
     PredArgs args;
@@ -491,9 +492,18 @@ ips_status emit_item(const ChainItem& it, int combine, const ips_column* cols, i
     if (c.max_def_level > 0) {
       // ColumnReader's nullable branch (hdfs-parquet-scanner.cc:338-345): the predicate over the
       // data rows, then IntersectBitset into the NOT-NULL positions, combined into the target
-      const NullableCol& nc = nctx.col[it.a->column];
+      NullableCol& nc = nctx.col[it.a->column];
       const int64_t n_sub = c.n_data_rows < n_rows ? c.n_data_rows : n_rows;
       args.combine = 0;
+      if (!nc.counted) {
+        nc.counted = true;
+        if (n_sub > 0) {
+          attach_rank_counts(&args, nc.root_kind, nc.root, n_rows, nc.tile_counts);
+        } else {
+          ips_status st = launch_rank_tile_counts(nc.root_kind, nc.root, n_rows, nc.tile_counts, s);
+          if (st != IPS_OK) return st;
+        }
+      }
       if (n_sub > 0) {
         ips_status st = launch_fle_pred(c.bit_width, reinterpret_cast<const uint64_t*>(c.d_data), n_sub,
                                         args, reinterpret_cast<uint32_t*>(nctx.sub), s);
@@ -612,7 +622,7 @@ ips_status run_plan(const Plan& pl, const ips_node* nodes, int n_nodes, const ip
         p += rank_workspace_bytes(n_rows) + slot_bytes;
         ips_status st = nullable_prepare_root(cols[c].d_def_levels, cols[c].def_bit_width,
                                               cols[c].max_def_level, n_rows, ws, &nctx.col[c].root_kind,
-                                              &nctx.col[c].root, s);
+                                              &nctx.col[c].root, s, /*count_tiles=*/false);
         if (st != IPS_OK) return st;
         nctx.col[c].tile_counts = ws.tile_counts;
       }

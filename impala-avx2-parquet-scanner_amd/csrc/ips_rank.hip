@@ -17,123 +17,15 @@
 //      bitmap (ips_eval_program's combine modes).
 // HBM traffic: def levels twice (n/8 bytes each), the data bitmap once in, the result once out.
 #include "ips_host.h"
+#include "ips_rank_device.h"
 
 namespace ips {
 
-constexpr int kRankThreads = 256;
-constexpr int kRankWaves = kRankThreads / kWave;
-constexpr int kRankRounds = 8;                                   // 16-byte loads per lane
-constexpr int kRankWordsPerWave = kWave * 2 * kRankRounds;        // 1024 words = 65536 rows
-constexpr int kRankWordsPerTile = kRankWordsPerWave * kRankWaves;  // 4096 words
-// expand_kernel works on quarter tiles: a workgroup takes the 1024 words one counting WAVE covered
-// (4 waves x 2 rounds), so the grid has 4x the blocks of the counting pass -- several generations
-// of workgroups per CU, whose load / deposit / store phases overlap (with one generation of
-// 4096-word blocks every wave of the chip was in the same phase: 38 -> 34 us for 2^28 rows)
-#ifndef IPS_EXP_ROUNDS
-#define IPS_EXP_ROUNDS 2
-#endif
-constexpr int kExpRounds = IPS_EXP_ROUNDS;
-constexpr int kExpWordsPerWave = kWave * 2 * kExpRounds;          // 256 words
-constexpr int kExpWordsPerBlock = kExpWordsPerWave * kRankWaves;   // 1024 words
-constexpr int kExpBlocksPerTile = kRankWordsPerTile / kExpWordsPerBlock;
-static_assert(kExpBlocksPerTile >= 1 && kRankWaves % kExpBlocksPerTile == 0, "an expand block is whole counting waves");
-
-typedef unsigned long long u64;
-
-// Root word i as a NOT-NULL mask in bitmap order, rows >= n_rows cleared.
-//   kRootBitmap: an ordinary bitmap word (LSB = first row)
-//   kRootLevels1: a width-1 FLE block of definition levels with max_def_level 1 (row k at bit
-//                 63-k, fle-encoding.h:8338-8340): the mask is the bit-reversed word
-enum RootKind { kRootBitmap = 0, kRootLevels1 = 1 };
-
-template <int ROOT>
-__device__ __forceinline__ u64 root_mask(u64 w, int64_t word, int64_t n_rows) {
-  if (ROOT == kRootLevels1) w = __builtin_bitreverse64(w);
-  const int64_t valid = n_rows - word * 64;
-  if (valid < 64) w = valid <= 0 ? 0ull : (w & ((1ull << valid) - 1ull));
-  return w;
-}
-
-// the wave's R x 2 root words from word 'first' on (word index of (round r, lane, e) =
-// first + r * 128 + 2 * lane + e), masked; words beyond n_words are zero
-template <int ROOT, int R>
-__device__ __forceinline__ void load_root(const u64* __restrict__ root, int64_t first,
-                                          int64_t n_words, int64_t n_rows, int lane,
-                                          u64 (&m)[R][2]) {
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int64_t w0 = first + r * 128 + 2 * lane;
-    u64 a = 0, b = 0;
-    if (w0 + 1 < n_words) {
-      u32x4 t = stream_load<true>(reinterpret_cast<const u32x4*>(root + w0));
-      a = ((u64)t.y << 32) | t.x;
-      b = ((u64)t.w << 32) | t.z;
-    } else if (w0 < n_words) {
-      a = root[w0];
-    }
-    m[r][0] = root_mask<ROOT>(a, w0, n_rows);
-    m[r][1] = root_mask<ROOT>(b, w0 + 1, n_rows);
-  }
-}
-
-// the same for a wave whose R x 128 words are all whole words of rows: no bounds, no row masks
-template <int ROOT, int R>
-__device__ __forceinline__ void load_root_whole(const u64* __restrict__ root, int64_t first, int lane,
-                                                u64 (&m)[R][2]) {
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const u32x4 t = stream_load<true>(reinterpret_cast<const u32x4*>(root + first + r * 128 + 2 * lane));
-    if (ROOT == kRootLevels1) {
-      m[r][0] = ((u64)__builtin_bitreverse32(t.x) << 32) | __builtin_bitreverse32(t.y);
-      m[r][1] = ((u64)__builtin_bitreverse32(t.z) << 32) | __builtin_bitreverse32(t.w);
-    } else {
-      m[r][0] = ((u64)t.y << 32) | t.x;
-      m[r][1] = ((u64)t.w << 32) | t.z;
-    }
-  }
-}
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
-  return __builtin_amdgcn_readlane(wave_inclusive_scan(x), 63);
-}
-
-// tile_counts[t] = set root bits of tile t; tile_counts[tiles + 4 t + w] = those of its wave w (the
-// quarter tiles expand_kernel works on).
-// ZERO: also clears the words of 'zero_out' that belong to the tile (the compress output must start
-// as zeros where two waves share a word; clearing it here saves a memset launch)
 template <int ROOT, bool ZERO>
 __global__ __launch_bounds__(kRankThreads) void rank_tile_counts_kernel(
     const u64* __restrict__ root, int64_t n_rows, uint32_t* __restrict__ tile_counts,
     u64* __restrict__ zero_out) {
-  __shared__ uint32_t wave_tot[kRankThreads / kWave];
-  const int lane = lane_id();
-  const int wave = wave_id();
-  const int64_t n_words = (n_rows + 63) / 64;
-  const int64_t first = (int64_t)blockIdx.x * kRankWordsPerTile + wave * kRankWordsPerWave;
-  u64 m[kRankRounds][2];
-  load_root<ROOT, kRankRounds>(root, first, n_words, n_rows, lane, m);
-  if (ZERO) {
-#pragma unroll
-    for (int r = 0; r < kRankRounds; ++r) {
-      const int64_t w0 = first + r * 128 + 2 * lane;
-      if (w0 + 1 < n_words) {
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4*>(zero_out + w0) = z;
-      } else if (w0 < n_words) {
-        zero_out[w0] = 0ull;
-      }
-    }
-  }
-  uint32_t c = 0;
-#pragma unroll
-  for (int r = 0; r < kRankRounds; ++r) c += __builtin_popcountll(m[r][0]) + __builtin_popcountll(m[r][1]);
-  const uint32_t tot = wave_sum(c);
-  if (lane == 0) {
-    wave_tot[wave] = tot;
-    tile_counts[gridDim.x + blockIdx.x * kRankWaves + wave] = tot;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) tile_counts[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  rank_tile_counts_body<ROOT, ZERO>(root, n_rows, tile_counts, blockIdx.x, gridDim.x, zero_out);
 }
 
 // pdep of the low popcount(mask) bits of src into the set positions of mask, four mask bits at a
@@ -549,7 +441,7 @@ NullableWs nullable_workspace(void* d_workspace, int64_t n_rows) {
 
 ips_status nullable_prepare_root(const void* d_def_levels, int def_bit_width, int max_def_level,
                                  int64_t n_rows, const NullableWs& ws, int* root_kind,
-                                 const uint64_t** root, hipStream_t s) {
+                                 const uint64_t** root, hipStream_t s, bool count_tiles) {
   if (def_bit_width == 1 && max_def_level == 1) {
     // the usual flat OPTIONAL column: the level words are the NOT-NULL bits
     *root_kind = kRootLevels1;
@@ -567,7 +459,18 @@ ips_status nullable_prepare_root(const void* d_def_levels, int def_bit_width, in
     *root_kind = kRootBitmap;
     *root = ws.nonnull;
   }
+  if (!count_tiles) return IPS_OK;
   return launch_rank_tile_counts(*root_kind, *root, n_rows, ws.tile_counts, s);
+}
+
+// the first rank_tiles(n_rows) workgroups of the predicate launch that takes 'args' count the tiles
+void attach_rank_counts(PredArgs* args, int root_kind, const uint64_t* root, int64_t n_rows,
+                        uint32_t* tile_counts) {
+  args->aux_blocks = (int32_t)rank_tiles(n_rows);
+  args->aux_kind = root_kind;
+  args->aux_root = root;
+  args->aux_rows = n_rows;
+  args->aux_counts = tile_counts;
 }
 
 }  // namespace ips
