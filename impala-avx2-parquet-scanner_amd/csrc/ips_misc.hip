@@ -1,6 +1,6 @@
-// ips_misc.hip -- the kernels that are not templated on the bit width: predicate-only FLE scan
-// (any w at run time), PLAIN-page predicates, bitmap algebra, IntersectBitset expand, batch
-// concatenation and the synthetic-column generator.  All HBM-bound streaming kernels.
+// ips_misc.hip -- bitmap algebra, batch concatenation, tuple assembly and the synthetic-column
+// generator (PLAIN pages: ips_plain.hip; rank-based bitmap kernels: ips_rank.hip).  All HBM-bound
+// streaming kernels.
 #include <string.h>
 
 #include "ips_host.h"
@@ -19,434 +19,6 @@ __device__ __forceinline__ T aux_load(const T* p) {
 template <typename T>
 __device__ __forceinline__ void aux_store(T* p, T v) {
   if (IPS_AUX_NT) __builtin_nontemporal_store(v, p); else *p = v;
-}
-
-// =============================================================================================
-// PLAIN fixed-width pages: ParquetPlainEncoder::Eq/Lt/Le/Gt/Ge (parquet-common.h:197-250, int8
-// :335-383, int16 :400-449).  bit = x OP literal (SQL order; the REFERENCE order is obtained by
-// the caller swapping LT<->GT, LE<->GE).  Lane loads 16 bytes = RPL rows; the RPL ballots are
-// re-interleaved into row order with a second round of ballots.
-// =============================================================================================
-template <typename T>
-struct PlainLit {
-  T v[16];
-  int32_t n;
-  int32_t combine;  // 0 set, 1 and-into, 2 or-into the bitmap
-  int32_t join;     // 0 none; 1 / 2: AND / OR with (x op2 v2) in the same pass
-  int32_t op2;
-  T v2;
-};
-
-template <typename T>
-__device__ __forceinline__ bool plain_cmp(T x, int op, const PlainLit<T>& lit) {
-  switch (op) {
-    case 0: return x == lit.v[0];
-    case 1: return x < lit.v[0];
-    case 2: return x <= lit.v[0];
-    case 3: return x > lit.v[0];
-    case 4: return x >= lit.v[0];
-    default: {
-      bool f = false;
-      for (int j = 0; j < lit.n; ++j) f = f || (x == lit.v[j]);
-      return f;
-    }
-  }
-}
-
-// T = compared type, S = slot type (int32_t for 4-byte slots, int64_t for 8-byte slots)
-template <typename T, typename S>
-__device__ __forceinline__ T slot_value(S raw) {
-  if constexpr (sizeof(T) == sizeof(S)) {
-    T t;
-    __builtin_memcpy(&t, &raw, sizeof(T));
-    return t;
-  } else {
-    return (T)raw;  // int8/int16: low bytes of the 4-byte slot, sign-extended by the cast
-  }
-}
-
-// A wave takes 8 consecutive chunks (8 KiB of the page) per iteration: the eight 16-byte loads of a
-// lane are issued back to back, and the 8*RPL bitmap words they produce leave as one contiguous
-// store (128 or 256 bytes) instead of eight small ones.
-constexpr int kPlainChunksPerTile = 8;
-
-template <typename T, typename S>
-__global__ __launch_bounds__(kThreads) void plain_pred_kernel(const S* __restrict__ page,
-                                                              int64_t n_rows, int op,
-                                                              PlainLit<T> lit,
-                                                              uint64_t* __restrict__ bitmap) {
-  constexpr int RPL = 16 / sizeof(S);  // rows per lane per load: 4 or 2
-  constexpr int U = kPlainChunksPerTile;
-  const int lane = lane_id();
-  const int64_t wave_g = (int64_t)blockIdx.x * kWavesPerBlock + wave_id();
-  const int64_t waves = (int64_t)gridDim.x * kWavesPerBlock;
-  const int64_t rows_per_chunk = 64 * RPL;
-  const int64_t rows_per_tile = rows_per_chunk * U;
-  const int64_t tiles = (n_rows + rows_per_tile - 1) / rows_per_tile;
-  const int64_t n_words = (n_rows + 63) / 64;
-
-  for (int64_t tile = wave_g; tile < tiles; tile += waves) {
-    const int64_t tile_row0 = tile * rows_per_tile;
-    S raw[U][RPL];
-    if (tile_row0 + rows_per_tile <= n_rows) {  // wave-uniform: full tile
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        u32x4 t = stream_load(reinterpret_cast<const u32x4*>(page + tile_row0 + u * rows_per_chunk + lane * RPL));
-        __builtin_memcpy(raw[u], &t, 16);
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t row0 = tile_row0 + u * rows_per_chunk + (int64_t)lane * RPL;
-#pragma unroll
-        for (int e = 0; e < RPL; ++e) raw[u][e] = row0 + e < n_rows ? page[row0 + e] : (S)0;
-      }
-    }
-    uint64_t mine = 0;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t row0 = tile_row0 + u * rows_per_chunk + (int64_t)lane * RPL;
-      uint64_t m[RPL];
-#pragma unroll
-      for (int e = 0; e < RPL; ++e) {
-        const T x = slot_value<T, S>(raw[u][e]);
-        bool b = plain_cmp<T>(x, op, lit);
-        if (lit.join != 0) {
-          PlainLit<T> l2;
-          l2.v[0] = lit.v2;
-          l2.n = 1;
-          const bool b2 = plain_cmp<T>(x, lit.op2, l2);
-          b = lit.join == 1 ? (b && b2) : (b || b2);
-        }
-        b = b && (row0 + e < n_rows);
-        m[e] = __builtin_amdgcn_ballot_w64(b);  // bit l <-> row RPL*l + e of the chunk
-      }
-      // row 64*j + t of the chunk sits in ballot (t % RPL) at bit (64*j + t) / RPL
-      uint64_t sel;
-      if (RPL == 4) sel = (lane & 2) ? ((lane & 1) ? m[3] : m[2]) : ((lane & 1) ? m[1] : m[0]);
-      else sel = (lane & 1) ? m[1] : m[0];
-#pragma unroll
-      for (int j = 0; j < RPL; ++j) {
-        int src = (64 * j + lane) / RPL;
-        uint64_t word = __builtin_amdgcn_ballot_w64(((sel >> src) & 1ull) != 0ull);
-        if (lane == u * RPL + j) mine = word;
-      }
-    }
-    const int64_t wi = tile * (U * RPL) + lane;
-    if (lane < U * RPL && wi < n_words) {
-      if (lit.combine == 1) mine &= bitmap[wi];
-      else if (lit.combine == 2) mine |= bitmap[wi];
-      IPS_BITMAP_STORE(bitmap + wi, mine);
-    }
-  }
-}
-
-// Fused scan of a PLAIN page: the predicate's bitmap AND the selected rows' slots in one pass over
-// the page (EvalSimplePredicates + ReadValue(skip) on the same column, hdfs-parquet-scanner.cc:
-// 1837-1865, 1006-1027; parquet-common.h:186-250).  A wave takes one 2048-row batch per iteration
-// (8 or 16 chunks of 16 bytes per lane); per chunk the lanes' selected slots are ranked with a DPP
-// prefix sum and stored straight to the batch, so row order is kept: chunk, lane, element.
-template <typename T, typename S>
-__global__ __launch_bounds__(kThreads) void plain_scan_kernel(const S* __restrict__ page,
-                                                              int64_t n_rows, int op,
-                                                              PlainLit<T> lit,
-                                                              uint64_t* __restrict__ bitmap,
-                                                              S* __restrict__ batch_values,
-                                                              uint32_t* __restrict__ batch_counts) {
-  constexpr int RPL = 16 / sizeof(S);           // rows per lane per load: 4 or 2
-  constexpr int U = kRowsPerTile / (64 * RPL);  // chunks per batch: 8 or 16
-  const int lane = lane_id();
-  const int64_t waves = (int64_t)gridDim.x * kWavesPerBlock;
-  const int64_t rows_per_chunk = 64 * RPL;
-  const int64_t n_batches = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
-  const int64_t n_words = (n_rows + 63) / 64;
-
-  for (int64_t batch = (int64_t)blockIdx.x * kWavesPerBlock + wave_id(); batch < n_batches;
-       batch += waves) {
-    const int64_t batch_row0 = batch * kRowsPerTile;
-    uint64_t mine = 0;
-    uint32_t base = 0;  // selected rows of the batch so far (wave-uniform)
-    S* dst = batch_values + batch_row0;
-    constexpr int UH = 8;  // chunks per round: 8 KiB in flight per wave, 32 page registers per lane
-#pragma unroll 1
-    for (int h = 0; h < U / UH; ++h) {
-      const int64_t round_row0 = batch_row0 + (int64_t)h * UH * rows_per_chunk;
-      S raw[UH][RPL];
-      if (round_row0 + UH * rows_per_chunk <= n_rows) {  // wave-uniform: full round
-#pragma unroll
-        for (int u = 0; u < UH; ++u) {
-          u32x4 t = stream_load(reinterpret_cast<const u32x4*>(page + round_row0 + u * rows_per_chunk + lane * RPL));
-          __builtin_memcpy(raw[u], &t, 16);
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < UH; ++u) {
-          const int64_t row0 = round_row0 + u * rows_per_chunk + (int64_t)lane * RPL;
-#pragma unroll
-          for (int e = 0; e < RPL; ++e) raw[u][e] = row0 + e < n_rows ? page[row0 + e] : (S)0;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UH; ++u) {
-        const int64_t row0 = round_row0 + u * rows_per_chunk + (int64_t)lane * RPL;
-        uint64_t m[RPL];
-        bool sel_e[RPL];
-#pragma unroll
-        for (int e = 0; e < RPL; ++e) {
-          const T x = slot_value<T, S>(raw[u][e]);
-          bool b = plain_cmp<T>(x, op, lit);
-          if (lit.join != 0) {
-            PlainLit<T> l2;
-            l2.v[0] = lit.v2;
-            l2.n = 1;
-            const bool b2 = plain_cmp<T>(x, lit.op2, l2);
-            b = lit.join == 1 ? (b && b2) : (b || b2);
-          }
-          b = b && (row0 + e < n_rows);
-          sel_e[e] = b;
-          m[e] = __builtin_amdgcn_ballot_w64(b);  // bit l <-> row RPL*l + e of the chunk
-        }
-        // bitmap words of the chunk (row 64*j + t sits in ballot (t % RPL) at bit (64*j + t) / RPL)
-        uint64_t sel;
-        if (RPL == 4) sel = (lane & 2) ? ((lane & 1) ? m[3] : m[2]) : ((lane & 1) ? m[1] : m[0]);
-        else sel = (lane & 1) ? m[1] : m[0];
-#pragma unroll
-        for (int j = 0; j < RPL; ++j) {
-          int src = (64 * j + lane) / RPL;
-          uint64_t word = __builtin_amdgcn_ballot_w64(((sel >> src) & 1ull) != 0ull);
-          if (lane == (h * UH + u) * RPL + j) mine = word;
-        }
-        // selected slots of the chunk, in row order.  The ballots already hold everything a prefix
-        // sum would compute: rows selected in lower lanes = mbcnt of each ballot, chunk total =
-        // scalar popcounts.
-        if ((m[0] | m[1] | (RPL == 4 ? (m[RPL - 2] | m[RPL - 1]) : 0ull)) != 0ull) {  // wave-uniform
-          uint32_t P = base;
-          uint32_t total = 0;
-#pragma unroll
-          for (int e = 0; e < RPL; ++e) {
-            P += __builtin_amdgcn_mbcnt_hi((uint32_t)(m[e] >> 32),
-                                           __builtin_amdgcn_mbcnt_lo((uint32_t)m[e], 0u));
-            total += (uint32_t)__builtin_popcountll(m[e]);
-          }
-#pragma unroll
-          for (int e = 0; e < RPL; ++e)
-            if (sel_e[e]) dst[P++] = raw[u][e];
-          base += total;
-        }
-      }
-    }
-    const int64_t wi = batch * 32 + lane;
-    if (lane < 32 && wi < n_words) IPS_BITMAP_STORE(bitmap + wi, mine);
-    if (lane == 0) batch_counts[batch] = base;
-  }
-}
-
-template <typename T, typename S>
-static ips_status launch_plain_scan_t(const void* page, int64_t n_rows, int op, const void* literals,
-                                      int n_literals, int join, int op2, const void* literal2,
-                                      uint64_t* bitmap, void* batch_values, uint32_t* batch_counts,
-                                      hipStream_t s) {
-  PlainLit<T> lit;
-  lit.n = n_literals;
-  lit.combine = 0;
-  lit.join = join;
-  lit.op2 = op2;
-  lit.v2 = literal2 ? *reinterpret_cast<const T*>(literal2) : T();
-  for (int i = 0; i < 16; ++i) lit.v[i] = i < n_literals ? reinterpret_cast<const T*>(literals)[i] : T();
-  const int64_t n_batches = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
-  int64_t want = (n_batches + kWavesPerBlock - 1) / kWavesPerBlock;
-  int64_t cap = (int64_t)device_cus() * 4 * grid_mult();
-  int grid = (int)(want < cap ? want : cap);
-  if (grid <= 0) return IPS_ERR_HIP;
-  hipLaunchKernelGGL((plain_scan_kernel<T, S>), dim3(grid), dim3(kThreads), 0, s,
-                     reinterpret_cast<const S*>(page), n_rows, op, lit, bitmap,
-                     reinterpret_cast<S*>(batch_values), batch_counts);
-  IPS_HIP_TRY(hipGetLastError());
-  return IPS_OK;
-}
-
-ips_status launch_plain_scan(int type, const void* page, int64_t n_rows, int op, const void* literals,
-                             int n_literals, int join, int op2, const void* literal2,
-                             uint64_t* bitmap, void* batch_values, uint32_t* batch_counts,
-                             hipStream_t s) {
-#define IPS_PS(T, S)                                                                              \
-  return launch_plain_scan_t<T, S>(page, n_rows, op, literals, n_literals, join, op2, literal2, \
-                                   bitmap, batch_values, batch_counts, s)
-  switch (type) {
-    case IPS_T_INT8: IPS_PS(int8_t, int32_t);
-    case IPS_T_INT16: IPS_PS(int16_t, int32_t);
-    case IPS_T_INT32: IPS_PS(int32_t, int32_t);
-    case IPS_T_INT64: IPS_PS(int64_t, int64_t);
-    case IPS_T_FLOAT: IPS_PS(float, int32_t);
-    case IPS_T_DOUBLE: IPS_PS(double, int64_t);
-  }
-#undef IPS_PS
-  set_error("plain_scan: bad type %d", type);
-  return IPS_ERR_INVALID_ARG;
-}
-
-template <typename T, typename S>
-static ips_status launch_plain_t(const void* page, int64_t n_rows, int op, const void* literals,
-                                 int n_literals, uint64_t* bitmap, hipStream_t s, int combine,
-                                 int join, int op2, const void* literal2) {
-  PlainLit<T> lit;
-  lit.n = n_literals;
-  lit.combine = combine;
-  lit.join = join;
-  lit.op2 = op2;
-  lit.v2 = literal2 ? *reinterpret_cast<const T*>(literal2) : T();
-  for (int i = 0; i < 16; ++i) lit.v[i] = i < n_literals ? reinterpret_cast<const T*>(literals)[i] : T();
-  constexpr int RPL = 16 / sizeof(S);
-  int64_t tiles = (n_rows + 64 * RPL * kPlainChunksPerTile - 1) / (64 * RPL * kPlainChunksPerTile);
-  int64_t want = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-  int64_t cap = (int64_t)device_cus() * 8 * grid_mult();
-  int grid = (int)(want < cap ? want : cap);
-  if (grid <= 0) return IPS_ERR_HIP;
-  hipLaunchKernelGGL((plain_pred_kernel<T, S>), dim3(grid), dim3(kThreads), 0, s,
-                     reinterpret_cast<const S*>(page), n_rows, op, lit, bitmap);
-  IPS_HIP_TRY(hipGetLastError());
-  return IPS_OK;
-}
-
-ips_status launch_plain_pred(int type, const void* page, int64_t n_rows, int op,
-                             const void* literals, int n_literals, uint64_t* bitmap,
-                             hipStream_t s, int combine, int join, int op2, const void* literal2) {
-#define IPS_PL(T, S) \
-  return launch_plain_t<T, S>(page, n_rows, op, literals, n_literals, bitmap, s, combine, join, op2, literal2)
-  switch (type) {
-    case IPS_T_INT8: IPS_PL(int8_t, int32_t);
-    case IPS_T_INT16: IPS_PL(int16_t, int32_t);
-    case IPS_T_INT32: IPS_PL(int32_t, int32_t);
-    case IPS_T_INT64: IPS_PL(int64_t, int64_t);
-    case IPS_T_FLOAT: IPS_PL(float, int32_t);
-    case IPS_T_DOUBLE: IPS_PL(double, int64_t);
-  }
-#undef IPS_PL
-  set_error("plain_pred: bad type %d", type);
-  return IPS_ERR_INVALID_ARG;
-}
-
-// =============================================================================================
-// Late materialisation on a PLAIN page: ReadValue(skip) -> ParquetPlainEncoder::Decode(buffer,
-// size, &val, skip_rows) per selected row (parquet-common.h:186-190, hdfs-parquet-scanner.cc:
-// 1006-1027).  One wave per 2048-row batch: lane l owns rows 32l..32l+31 of the batch (one bitmap
-// dword), a DPP prefix sum of the popcounts gives its first output slot, then it walks its set
-// bits four at a time -- four independent slot loads in flight -- and stores them in row order.
-// Same batch layout as ips_fle_select.
-// =============================================================================================
-constexpr uint32_t kPlainSelectStreamMin = 64;  // selected rows per 2048-row batch (3 %)
-
-template <typename S>
-__global__ __launch_bounds__(kThreads) void plain_select_kernel(
-    const S* __restrict__ page, int64_t n_rows, const uint32_t* __restrict__ bitmap32,
-    S* __restrict__ batch_values, uint32_t* __restrict__ batch_counts) {
-  const int lane = lane_id();
-  const int64_t n_batches = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
-  const int64_t bm_dwords = bitmap_dwords(n_rows);
-  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
-  for (int64_t batch = (int64_t)blockIdx.x * kWavesPerBlock + wave_id(); batch < n_batches;
-       batch += stride) {
-    const int64_t d = batch * 64 + lane;
-    uint32_t m = d < bm_dwords ? bitmap32[d] : 0u;
-    const int64_t row0 = batch * kRowsPerTile + (int64_t)lane * 32;
-    const int64_t valid = n_rows - row0;
-    if (valid < 32) m = valid <= 0 ? 0u : (m & ((1u << valid) - 1u));
-    const uint32_t mine = (uint32_t)__builtin_popcount(m);
-    const uint32_t incl = wave_inclusive_scan(mine);
-    const uint32_t count = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    uint32_t P = incl - mine;
-    const S* src = page + row0;
-    S* dst = batch_values + batch * kRowsPerTile;
-    // Above a few per cent selectivity nearly every 128-byte line of the batch holds a selected
-    // row (10 %: 81 % of the lines of an 8-byte column), and fetching them through scattered
-    // 8-byte loads costs far more than their bytes: stream the whole batch with coalesced 16-byte
-    // loads instead and rank the selected slots with the ballots of their bitmap bits (the
-    // materialisation half of plain_scan_kernel).  Wave-uniform choice per batch.
-    constexpr int RPL = 16 / (int)sizeof(S);
-    constexpr int U = kRowsPerTile / (64 * RPL);
-    constexpr int UH = 8;
-    const int64_t batch_row0 = batch * kRowsPerTile;
-    if (count >= kPlainSelectStreamMin && batch_row0 + kRowsPerTile <= n_rows) {
-      uint32_t base = 0;
-#pragma unroll 1
-      for (int h = 0; h < U / UH; ++h) {
-        S raw[UH][RPL];
-        uint32_t bits[UH];
-#pragma unroll
-        for (int u = 0; u < UH; ++u) {
-          const int r = (h * UH + u) * 64 * RPL + lane * RPL;  // first row of this lane's load
-          u32x4 t = stream_load(reinterpret_cast<const u32x4*>(page + batch_row0 + r));
-          __builtin_memcpy(raw[u], &t, 16);
-          bits[u] = bitmap32[batch * 64 + (r >> 5)] >> (r & 31);
-        }
-#pragma unroll
-        for (int u = 0; u < UH; ++u) {
-          uint64_t mm[RPL];
-          bool sel_e[RPL];
-#pragma unroll
-          for (int e = 0; e < RPL; ++e) {
-            sel_e[e] = ((bits[u] >> e) & 1u) != 0u;
-            mm[e] = __builtin_amdgcn_ballot_w64(sel_e[e]);
-          }
-          uint64_t any = mm[0];
-#pragma unroll
-          for (int e = 1; e < RPL; ++e) any |= mm[e];
-          if (any != 0ull) {  // wave-uniform
-            uint32_t Q = base;
-            uint32_t total = 0;
-#pragma unroll
-            for (int e = 0; e < RPL; ++e) {
-              Q += __builtin_amdgcn_mbcnt_hi((uint32_t)(mm[e] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm[e], 0u));
-              total += (uint32_t)__builtin_popcountll(mm[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < RPL; ++e)
-              if (sel_e[e]) dst[Q++] = raw[u][e];
-            base += total;
-          }
-        }
-      }
-      if (lane == 0) batch_counts[batch] = count;
-      continue;
-    }
-    while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
-      S x[4];
-      bool ok[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        ok[e] = m != 0u;
-        x[e] = ok[e] ? src[__builtin_ctz(m)] : (S)0;
-        m &= m - 1u;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (ok[e]) dst[P++] = x[e];
-      }
-    }
-    if (lane == 0) batch_counts[batch] = count;
-  }
-}
-
-ips_status launch_plain_select(int stride_bytes, const void* page, int64_t n_rows,
-                               const uint64_t* bitmap, void* batch_values, uint32_t* batch_counts,
-                               hipStream_t s) {
-  const int64_t n_batches = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
-  if (n_batches <= 0) return IPS_OK;
-  int64_t want = (n_batches + kWavesPerBlock - 1) / kWavesPerBlock;
-  int64_t cap = (int64_t)device_cus() * 8 * grid_mult();
-  const int grid = (int)(want < cap ? want : cap);
-  if (stride_bytes == 4)
-    hipLaunchKernelGGL((plain_select_kernel<uint32_t>), dim3(grid), dim3(kThreads), 0, s,
-                       reinterpret_cast<const uint32_t*>(page), n_rows,
-                       reinterpret_cast<const uint32_t*>(bitmap),
-                       reinterpret_cast<uint32_t*>(batch_values), batch_counts);
-  else
-    hipLaunchKernelGGL((plain_select_kernel<uint64_t>), dim3(grid), dim3(kThreads), 0, s,
-                       reinterpret_cast<const uint64_t*>(page), n_rows,
-                       reinterpret_cast<const uint32_t*>(bitmap),
-                       reinterpret_cast<uint64_t*>(batch_values), batch_counts);
-  IPS_HIP_TRY(hipGetLastError());
-  return IPS_OK;
 }
 
 // =============================================================================================
