@@ -364,6 +364,18 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
   return x;
 }
 
+// Wave-wide maximum (same DPP steps as the scan; the result is wave-uniform).
+__device__ __forceinline__ uint32_t wave_max(uint32_t x) {
+  auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+  x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true));   // row_shr:1
+  x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true));   // row_shr:2
+  x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true));   // row_shr:4
+  x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true));   // row_shr:8
+  x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false));  // row_bcast:15
+  x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false));  // row_bcast:31
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
 // Dense compaction image: element P of the sub-tile's selected rows lives at dword P + P/32 of the
 // wave's LDS region.  The one-dword pad per 32 elements keeps the per-lane scatter below
 // conflict-free up to 100 % selectivity (lane l writes element 32*l + j in step j: bank

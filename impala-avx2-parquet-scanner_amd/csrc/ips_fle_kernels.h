@@ -191,8 +191,11 @@ __device__ __forceinline__ void fle_scan_body(
       given_nxt = given_nn;
     }
 
+#ifndef IPS_ABLATE
+#define IPS_ABLATE 0  // dev: 1 no phase A/B, 2 nothing after the bitmap store, 3 no phase B (results are wrong)
+#endif
     uint32_t count = 0;
-    if (__builtin_amdgcn_ballot_w64(bm != 0u) != 0ull) {  // wave-uniform: any row selected
+    if (IPS_ABLATE != 2 && __builtin_amdgcn_ballot_w64(bm != 0u) != 0ull) {  // wave-uniform: any row selected
       const uint32_t mine = (uint32_t)__builtin_popcount(bm);
       const uint32_t incl = wave_inclusive_scan(mine);
       count = __builtin_amdgcn_readlane(incl, 63);
@@ -293,44 +296,59 @@ __device__ __forceinline__ void fle_scan_body(
         // straight-line round -- lowest set bit, store under the exec mask, clear it -- until no
         // lane has a bit left; finished lanes keep clearing zero.
         uint16_t* list = reinterpret_cast<uint16_t*>(lds8 + kRowTileBytes);
-        {
+#ifndef IPS_PHASE_A_UNIFORM
+#define IPS_PHASE_A_UNIFORM 1  // trip count = the wave's largest popcount (one DPP max), no ballot per round
+#endif
+#ifndef IPS_PHASE_B_GROUP
+#define IPS_PHASE_B_GROUP 4    // rounds whose LDS reads are issued together
+#endif
+        if (IPS_ABLATE != 1) {
           uint32_t m = bm;
           uint16_t* slot = list + P;
           const uint32_t lane5 = (uint32_t)lane << 5;
-          do {
-            if (m != 0u) *slot = (uint16_t)(lane5 | (uint32_t)__builtin_ctz(m));
-            ++slot;
-            m &= m - 1u;
-          } while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull);
+          if (IPS_PHASE_A_UNIFORM) {
+            const uint32_t trips = wave_max(mine);  // scalar loop control: nothing waits for a ballot
+            for (uint32_t t = 0; t < trips; ++t) {
+              if (m != 0u) *slot = (uint16_t)(lane5 | (uint32_t)__builtin_ctz(m));
+              ++slot;
+              m &= m - 1u;
+            }
+          } else {
+            do {
+              if (m != 0u) *slot = (uint16_t)(lane5 | (uint32_t)__builtin_ctz(m));
+              ++slot;
+              m &= m - 1u;
+            } while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull);
+          }
         }
         wave_lds_fence();
-        // phase B: 64 entries per round, all lanes busy: entry -> LDS offset of the value -> slot
+        // phase B: 64 entries per round, all lanes busy: entry -> LDS offset of the value -> slot.
+        // The rounds are taken in groups of four whose list reads, then value reads, are issued
+        // back to back (a round is two dependent LDS round trips; one after the other they were
+        // most of the phase's time).
         int bad = 0;
-        const uint32_t rounds = (count + kWave - 1) / kWave;  // wave-uniform trip count
-        for (uint32_t rd = 0; rd < rounds; ++rd) {
-          const uint32_t i = rd * kWave + lane;
-          if (i >= count) continue;  // only lanes of the last round
-          const uint32_t e = list[i];
+        auto value_at = [&](uint32_t e) -> uint32_t {
           const uint32_t src = e >> 5, j = e & 31u;
-          uint32_t x;
           if (kQuads) {
             const uint32_t b = 31u - j;  // row j sits at bit position 31 - j
             const u32x4 q = *reinterpret_cast<const u32x4*>(lds32 + src * kRowTileStrideDw + (b & ~3u));
-            x = quads_value(q.x, q.y, q.z, q.w, b & 3u);
+            return quads_value(q.x, q.y, q.z, q.w, b & 3u);
           } else if (!kPacked) {
-            x = lds32[src * kRowTileStrideDw + j];
+            return lds32[src * kRowTileStrideDw + j];
           } else if (kQuads16) {
             const uint32_t b = 31u - j;
             const u32x4 q = *reinterpret_cast<const u32x4*>(lds8 + src * kStride + 4u * (b & 12u));
-            x = quads_value(q.x, q.y, q.z, q.w, (b & 16u) | (b & 3u), 0x1111u);
+            return quads_value(q.x, q.y, q.z, q.w, (b & 16u) | (b & 3u), 0x1111u);
           } else if (R == 16) {
-            x = *reinterpret_cast<const uint16_t*>(lds8 + src * kStride + 4u * ((31u - j) & 15u) + 2u * ((31u - j) >> 4));
+            return *reinterpret_cast<const uint16_t*>(lds8 + src * kStride + 4u * ((31u - j) & 15u) + 2u * ((31u - j) >> 4));
           } else {
-            x = lds8[src * kStride + 4u * ((31u - j) & 7u) + ((31u - j) >> 3)];
+            return lds8[src * kStride + 4u * ((31u - j) & 7u) + ((31u - j) >> 3)];
           }
+        };
 #ifndef IPS_NT_VALUE_STORE
 #define IPS_NT_VALUE_STORE 0
 #endif
+        auto put = [&](uint32_t i, uint32_t x) {
           if (G == 0) {
             if (IPS_NT_VALUE_STORE) __builtin_nontemporal_store((GT)x, dst + i);
             else dst[i] = (GT)x;
@@ -339,6 +357,23 @@ __device__ __forceinline__ void fle_scan_body(
             else dst[i] = lookup(x);
           } else {
             bad = 1;
+          }
+        };
+        constexpr uint32_t kGroup = IPS_PHASE_B_GROUP;
+        const uint32_t n_out = (IPS_ABLATE == 1 || IPS_ABLATE == 3) ? 0u : count;
+        for (uint32_t g0 = 0; g0 < n_out; g0 += kGroup * kWave) {  // wave-uniform
+          uint32_t e[kGroup], x[kGroup];
+#pragma unroll
+          for (uint32_t k = 0; k < kGroup; ++k) {
+            const uint32_t i = g0 + k * kWave + lane;
+            e[k] = list[i < n_out ? i : 0u];
+          }
+#pragma unroll
+          for (uint32_t k = 0; k < kGroup; ++k) x[k] = value_at(e[k]);
+#pragma unroll
+          for (uint32_t k = 0; k < kGroup; ++k) {
+            const uint32_t i = g0 + k * kWave + lane;
+            if (i < n_out) put(i, x[k]);
           }
         }
         if (G != 0 && bad && bad_index) *bad_index = 1;

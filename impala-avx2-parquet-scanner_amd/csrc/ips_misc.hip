@@ -351,7 +351,61 @@ constexpr int kTupleImageMax = 128;  // tuples up to this size are staged throug
 // straight to HBM.
 // FAST: every column REQUIRED, 4 bytes wide and 4-byte aligned in the tuple (the common layout):
 // the column loop is unrolled with constant indices, all slot loads of a round are issued before
-// the first one is consumed.
+// the first one is consumed.  (Tuples of at most 16 bytes of this kind: assemble_small_kernel.)
+// The image is padded by one dword per 64 (img()): lane i writes dword d of its tuple at logical
+// dword i * ts / 4 + d, which for 16 / 32 / 64-byte tuples put 4 / 8 / 16 lanes on every bank
+// (68 % of the LDS cycles of the 16-byte case were conflicts); with the pad, lanes whose logical
+// dwords are 64 apart land on neighbouring banks, and the linear read-out stays conflict-free.
+__device__ __forceinline__ uint32_t img(uint32_t byte) { return byte + ((byte >> 8) << 2); }
+
+// FAST tuples of at most 16 bytes never touch LDS: the lane builds its tuple in registers and the
+// 64 tuples of a round leave as one coalesced store (4 / 8 / 12 / 16 bytes per lane).  Its own
+// kernel with a compact argument block: inside assemble_tuples_kernel the scalar registers that
+// TupleCols occupies spilled.
+struct SmallTupleCols {
+  const uint32_t* values[IPS_TUPLE_MAX_COLS];
+  int32_t dword[IPS_TUPLE_MAX_COLS];  // tuple_offset / 4
+  uint32_t tmpl[4];
+  int32_t n_cols;
+  int32_t tuple_size;
+};
+
+template <int TS>
+__global__ __launch_bounds__(kThreads) void assemble_small_kernel(
+    SmallTupleCols tc, const uint32_t* __restrict__ counts, int64_t n_batches,
+    const uint64_t* __restrict__ batch_off, uint8_t* __restrict__ tuples) {
+  const int lane = lane_id();
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t batch = (int64_t)blockIdx.x * kWavesPerBlock + wave_id(); batch < n_batches; batch += stride) {
+    const uint32_t cnt = counts[batch];
+    const uint64_t first = batch_off[batch];
+    for (uint32_t i0 = 0; i0 < cnt; i0 += kWave) {
+      const uint32_t i = i0 + lane;
+      if (i >= cnt) continue;
+      const uint64_t src = (uint64_t)batch * kRowsPerTile + i;
+      uint32_t w[4] = {tc.tmpl[0], tc.tmpl[1], tc.tmpl[2], tc.tmpl[3]};
+      for (int col = 0; col < tc.n_cols; ++col) {  // wave-uniform trip count and slot positions
+        const uint32_t x = aux_load(tc.values[col] + src);
+        const int d = tc.dword[col];
+        w[0] = d == 0 ? x : w[0];
+        w[1] = d == 1 ? x : w[1];
+        w[2] = d == 2 ? x : w[2];
+        w[3] = d == 3 ? x : w[3];
+      }
+      uint8_t* o = tuples + (first + i) * (uint64_t)TS;
+      if (TS == 16) {
+        const u32x4 v = {w[0], w[1], w[2], w[3]};
+        aux_store(reinterpret_cast<u32x4*>(o), v);
+      } else if (TS == 8) {
+        *reinterpret_cast<uint64_t*>(o) = ((uint64_t)w[1] << 32) | w[0];
+      } else {
+#pragma unroll
+        for (int d = 0; d < TS / 4; ++d) reinterpret_cast<uint32_t*>(o)[d] = w[d];
+      }
+    }
+  }
+}
+
 template <bool IMAGE, bool FAST>
 __global__ __launch_bounds__(kThreads) void assemble_tuples_kernel(
     TupleCols tc, const uint32_t* __restrict__ counts, int64_t n_batches,
@@ -360,7 +414,7 @@ __global__ __launch_bounds__(kThreads) void assemble_tuples_kernel(
   const int lane = lane_id();
   const int wave = wave_id();
   const int ts = tc.tuple_size;
-  uint8_t* image = image_all + (IMAGE ? wave * kWave * ts : 0);
+  uint8_t* image = image_all + (IMAGE ? wave * (int)img((uint32_t)(kWave * ts)) : 0);
   const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
   for (int64_t batch = (int64_t)blockIdx.x * kWavesPerBlock + wave; batch < n_batches;
        batch += stride) {
@@ -369,11 +423,14 @@ __global__ __launch_bounds__(kThreads) void assemble_tuples_kernel(
     for (uint32_t i0 = 0; i0 < cnt; i0 += kWave) {
       const uint32_t i = i0 + lane;
       const uint32_t in_round = cnt - i0 < (uint32_t)kWave ? cnt - i0 : (uint32_t)kWave;
-      uint8_t* t = IMAGE ? image + lane * ts : tuples + (first + i) * (uint64_t)ts;
+      // the lane's tuple: image + img(lane * ts + byte) (IMAGE) or its place in the output
+      const uint32_t t0 = (uint32_t)(lane * ts);
+      uint8_t* t = IMAGE ? image : tuples + (first + i) * (uint64_t)ts;
+      auto at = [&](int byte) -> uint8_t* { return IMAGE ? image + img(t0 + (uint32_t)byte) : t + byte; };
       if (IMAGE) {
 #pragma unroll
         for (int d = 0; d < kTupleImageMax / 4; ++d)
-          if (4 * d < ts) reinterpret_cast<uint32_t*>(t)[d] = tc.tmpl[d];
+          if (4 * d < ts) *reinterpret_cast<uint32_t*>(at(4 * d)) = tc.tmpl[d];
       } else if (i < cnt) {
         for (int d = 0; d < ts; ++d) t[d] = tc.d_template[d];
       }
@@ -386,7 +443,7 @@ __global__ __launch_bounds__(kThreads) void assemble_tuples_kernel(
         if (i < cnt) {
 #pragma unroll
           for (int col = 0; col < IPS_TUPLE_MAX_COLS; ++col)
-            if (col < tc.n_cols) *reinterpret_cast<uint32_t*>(t + tc.offset[col]) = x[col];
+            if (col < tc.n_cols) *reinterpret_cast<uint32_t*>(at(tc.offset[col])) = x[col];
         }
       } else if (i < cnt) {
         const uint64_t gi = first + i;  // index of this tuple among all selected rows
@@ -395,24 +452,27 @@ __global__ __launch_bounds__(kThreads) void assemble_tuples_kernel(
           if (tc.flags[col]) {  // OPTIONAL column: NULL bit, or the rank-th dense value
             const uint64_t fw = tc.flags[col][gi >> 6];
             if (!((fw >> (gi & 63)) & 1ull)) {
-              t[tc.null_byte[col]] |= (uint8_t)tc.null_mask[col];
+              *at(tc.null_byte[col]) |= (uint8_t)tc.null_mask[col];
               continue;
             }
             src = tc.prefix[col][gi >> 6] + __builtin_popcountll(fw & ((1ull << (gi & 63)) - 1ull));
           }
-          uint8_t* slot = t + tc.offset[col];
-          const bool aligned = ((tc.offset[col] | ts) & 3) == 0;  // slots are naturally aligned in Impala tuples
+          const int so = tc.offset[col];
+          const bool aligned = ((so | ts) & 3) == 0;  // slots are naturally aligned in Impala tuples
           if (tc.width[col] == 4) {
             const uint32_t x = reinterpret_cast<const uint32_t*>(tc.values[col])[src];
-            if (aligned) *reinterpret_cast<uint32_t*>(slot) = x;
-            else __builtin_memcpy(slot, &x, 4);
+            if (aligned) {
+              *reinterpret_cast<uint32_t*>(at(so)) = x;
+            } else {
+              for (int k = 0; k < 4; ++k) *at(so + k) = (uint8_t)(x >> (8 * k));
+            }
           } else {
             const uint64_t x = reinterpret_cast<const uint64_t*>(tc.values[col])[src];
             if (aligned) {
-              reinterpret_cast<uint32_t*>(slot)[0] = (uint32_t)x;
-              reinterpret_cast<uint32_t*>(slot)[1] = (uint32_t)(x >> 32);
+              *reinterpret_cast<uint32_t*>(at(so)) = (uint32_t)x;
+              *reinterpret_cast<uint32_t*>(at(so + 4)) = (uint32_t)(x >> 32);
             } else {
-              __builtin_memcpy(slot, &x, 8);
+              for (int k = 0; k < 8; ++k) *at(so + k) = (uint8_t)(x >> (8 * k));
             }
           }
         }
@@ -422,11 +482,14 @@ __global__ __launch_bounds__(kThreads) void assemble_tuples_kernel(
         uint8_t* dst = tuples + (first + i0) * (uint64_t)ts;
         const uint32_t bytes = in_round * (uint32_t)ts;
         if ((ts & 15) == 0) {  // 16-byte pieces: the destination is 16-byte aligned as well
-          for (uint32_t o = lane * 16; o < bytes; o += kWave * 16)
-            aux_store(reinterpret_cast<u32x4*>(dst + o), *reinterpret_cast<const u32x4*>(image + o));
+          for (uint32_t o = lane * 16; o < bytes; o += kWave * 16) {
+            const uint32_t* src4 = reinterpret_cast<const uint32_t*>(image + img(o));  // a piece never straddles a pad
+            const u32x4 v = {src4[0], src4[1], src4[2], src4[3]};
+            aux_store(reinterpret_cast<u32x4*>(dst + o), v);
+          }
         } else {
           for (uint32_t o = lane * 4; o < bytes; o += kWave * 4)
-            *reinterpret_cast<uint32_t*>(dst + o) = *reinterpret_cast<const uint32_t*>(image + o);
+            *reinterpret_cast<uint32_t*>(dst + o) = *reinterpret_cast<const uint32_t*>(image + img(o));
         }
         wave_lds_fence();
       }
@@ -502,9 +565,23 @@ ips_status launch_assemble_tuples(const ips_tuple_column* cols, int n_cols, cons
   bool fast = image;
   for (int i = 0; i < n_cols; ++i)
     fast = fast && !cols[i].d_nonnull_flags && cols[i].value_width == 4 && (cols[i].tuple_offset & 3) == 0;
-  const size_t lds = image ? (size_t)kWavesPerBlock * kWave * tuple_size : 0;
+  const size_t wave_image = (size_t)kWave * tuple_size;
+  const size_t lds = image ? (size_t)kWavesPerBlock * (wave_image + ((wave_image >> 8) << 2)) : 0;
   uint8_t* out = reinterpret_cast<uint8_t*>(tuples);
-  if (fast)
+  if (fast && tuple_size <= 16) {
+    SmallTupleCols sc;
+    memset(&sc, 0, sizeof(sc));
+    for (int i = 0; i < n_cols; ++i) {
+      sc.values[i] = reinterpret_cast<const uint32_t*>(tc.values[i]);
+      sc.dword[i] = tc.offset[i] >> 2;
+    }
+    memcpy(sc.tmpl, tc.tmpl, (size_t)tuple_size);
+    sc.n_cols = n_cols;
+    sc.tuple_size = tuple_size;
+#define IPS_SMALL(TS) hipLaunchKernelGGL((assemble_small_kernel<TS>), dim3(grid), dim3(kThreads), 0, s, sc, counts, n_batches, batch_off, out)
+    if (tuple_size == 16) IPS_SMALL(16); else if (tuple_size == 12) IPS_SMALL(12); else if (tuple_size == 8) IPS_SMALL(8); else IPS_SMALL(4);
+#undef IPS_SMALL
+  } else if (fast)
     hipLaunchKernelGGL((assemble_tuples_kernel<true, true>), dim3(grid), dim3(kThreads), lds, s, tc,
                        counts, n_batches, batch_off, out);
   else if (image)
