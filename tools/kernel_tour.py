@@ -70,7 +70,7 @@ bm = torch.empty(W, dtype=torch.int64, device=dev)
 nodes = [capi.plain_leaf(0, capi.OP_GE, np.int64(lo), capi.T_INT64), capi.plain_leaf(0, capi.OP_LE, np.int64(hi), capi.T_INT64),
          capi.and_node()]
 cols = [capi.plain_column(page, capi.T_INT64)]
-run("plain_pred int64 BETWEEN @10%", "plain_pred_kernel<long", 8 * n + n // 8, lambda: capi.eval_program(nodes, cols, n, bitmap=bm))
+run("plain_pred int64 BETWEEN @10%", "plain_tile_kernel<long, unsigned long, false>", 8 * n + n // 8, lambda: capi.eval_program(nodes, cols, n, bitmap=bm))
 res = {}
 
 
@@ -80,7 +80,7 @@ def pscan():
 
 pscan()
 nsel = int(res["r"][2].to(torch.int64).sum().item())
-run("plain_scan int64 BETWEEN @10%", "plain_scan_kernel<long", 8 * n + n // 8 + 8 * nsel, pscan)
+run("plain_scan int64 BETWEEN @10%", "plain_tile_kernel<long, unsigned long, true>", 8 * n + n // 8 + 8 * nsel, pscan)
 del res
 run("plain_select int64 @10%", "plain_select_kernel<unsigned long", n // 8 + 16 * nsel, lambda: capi.plain_select(page, n, capi.T_INT64, bm))
 del page
@@ -104,8 +104,8 @@ cnt = torch.zeros(2, dtype=torch.int64, device=dev)
 dense = torch.empty(n, dtype=torch.int32, device=dev)
 run("bitmap_and", "bitmap_binop_kernel", 3 * W * 8, lambda: lib.ips_bitmap_and(P(acc), P(bm50), N, S))
 run("bitmap_count", "bitmap_count_kernel", W * 8, lambda: lib.ips_bitmap_count(P(bm10), N, P(cnt), S))
-run("bitmap_expand (root 50%)", "expand_kernel<0>", 3 * W * 8, lambda: lib.ips_bitmap_expand(P(bm50), P(bm10), N, P(out_bm), P(ws), S))
-run("bitmap_compress (mask 50%)", "bitmap_compress_kernel", 3 * W * 8,
+run("bitmap_expand (root 50%)", "expand_kernel<0, 0>", 3 * W * 8, lambda: lib.ips_bitmap_expand(P(bm50), P(bm10), N, P(out_bm), P(ws), S))
+run("bitmap_compress (mask 50%)", "compress_kernel<0, 0>", 3 * W * 8,
     lambda: lib.ips_bitmap_compress(P(bm50), P(bm10), N, P(out_bm), P(cnt), P(ws), S))
 run("batches_compact @10%", "batches_compact_kernel", 8 * nsel + counts.numel() * 4,
     lambda: lib.ips_batches_compact(P(bvals), P(counts), N, 4, P(dense), P(cnt), P(ws), S))
@@ -113,7 +113,7 @@ tc = (capi.TupleColumn * 3)()
 for i in range(3):
     tc[i].d_batch_values, tc[i].value_width, tc[i].tuple_offset = bvals.data_ptr(), 4, 4 * i
 tuples = torch.empty(nsel * 16 + 64, dtype=torch.uint8, device=dev)
-run("assemble_tuples 3 x int32 -> 16 B", "assemble_tuples_kernel", nsel * 28 + counts.numel() * 4,
+run("assemble_tuples 3 x int32 -> 16 B", "assemble_small_kernel<16>", nsel * 28 + counts.numel() * 4,
     lambda: lib.ips_assemble_tuples(tc, 3, P(counts), N, 16, None, P(tuples), P(cnt), P(ws), S))
 del vals, enc, outs, bm50, acc, tuples, dense
 
@@ -146,7 +146,7 @@ del is_set
 venc = capi.fle_encode(capi.synth_u32(0x5EED0D2, k, 12), 12)
 n_data = ((k + 63) // 64) * 64
 wsn = capi.nullable_workspace(n, dev)
-run("nullable leaf w=12, 10% NULL (pred + expand)", "expand_kernel<1>", W * 16 + n_data // 64 * 96,
+run("nullable leaf w=12, 10% NULL (pred + expand)", "expand_kernel<1, 0>", W * 16 + n_data // 64 * 96,
     lambda: capi.fle_pred_nullable(defs, 1, 1, n, venc, n_data, 12, capi.OP_LT, 409, bitmap=bm, workspace=wsn))
 del defs, venc, wsn
 

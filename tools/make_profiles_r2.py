@@ -136,7 +136,7 @@ with open(os.path.join(dst, f"{tag}_kernel_tour.md"), "w") as f:
     fix = {"fle_pred w=32 BETWEEN": "fle_pred32_early_kernel<32, true>", "fle_pred w=16 BETWEEN": "fle_pred_w_kernel<16, 1>",
            "fle_pred w=8 BETWEEN": "fle_pred_w_kernel<8, 1>", "fle_pred w=16 LT": "fle_pred_w_kernel<16, 0>",
            "fle_pred w=8 LT": "fle_pred_w_kernel<8, 0>", "fle_pred w=32 LT": "fle_pred32_early_kernel<32, false>",
-           "nullable leaf w=12, 10% NULL (pred + expand)": "expand_kernel<1>", "bitmap_expand (root 50%)": "expand_kernel<0>",
+           "nullable leaf w=12, 10% NULL (pred + expand)": "expand_kernel<1, 0>", "bitmap_expand (root 50%)": "expand_kernel<0, 0>",
            "Q6 conjunction, 3 columns (3 launches)": "fle_pred_w_kernel<12, 1>"}
     for t in tour:
         t["kernel"] = fix.get(t["op"], t["kernel"])
