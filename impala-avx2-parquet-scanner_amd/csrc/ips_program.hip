@@ -12,6 +12,9 @@
 #include <mutex>
 #include <utility>
 
+#include <map>
+#include <mutex>
+
 #include "ips_host.h"
 
 namespace ips {
@@ -371,29 +374,35 @@ struct ChainOp {
 template <int N>
 struct ChainArgs { ChainOp ops[N]; };
 
-template <int N>
-__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_chain_kernel(
-    ChainArgs<N> a, int64_t n_rows, uint32_t* __restrict__ bitmap32) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * plane_tile_bytes(32) / 4];
+// LMAX = 16-byte loads per lane of the widest operand (2: w <= 8, 4: w <= 16, 8: any), image_dwords
+// = its LDS image per wave (dynamic shared memory): a chain of narrow columns keeps the occupancy
+// of the narrow predicate kernels.  (First version: both sized for w = 32, the operand loop
+// unrolled with all descriptors in scalar registers -- 140 of them spilled: 418 us on the Q6 chain
+// against 344 us for three launches; now 344 us as well.  Tried on top, no gain: descriptors kept in
+// scalar registers with the IN lists left in memory, the bytes of two steps in flight.)
+template <int N, int LMAX>
+__global__ __launch_bounds__(kThreads, LMAX <= 4 ? 6 : IPS_MIN_WAVES_PER_EU) void fle_chain_kernel(
+    ChainArgs<N> a, int64_t n_rows, uint32_t* __restrict__ bitmap32, int image_dwords) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
   const int lane = lane_id();
   const int wave = wave_id();
-  uint32_t* lds32 = lds_all + wave * (plane_tile_bytes(32) / 4);
+  uint32_t* lds32 = lds_all + wave * image_dwords;
   const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
   const int64_t bm_dwords = bitmap_dwords(n_rows);
   int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-  u32x4 r[8];
+  u32x4 r[LMAX];
   auto load = [&](int i, int64_t t) {
-    tile_load<8>(a.ops[i].enc, t, a.ops[i].w, ((n_rows + 63) / 64) * a.ops[i].w, lane, r);
+    tile_load<LMAX>(a.ops[i].enc, t, a.ops[i].w, ((n_rows + 63) / 64) * a.ops[i].w, lane, r);
   };
   if (tile < tiles) load(0, tile);
   while (tile < tiles) {
     const int64_t next = tile + stride;
     uint32_t acc = 0u;
-#pragma unroll
+#pragma unroll 1  // the descriptor of an operand is read from the kernel arguments when its turn comes
     for (int i = 0; i < N; ++i) {
       const ChainOp& o = a.ops[i];
-      tile_to_lds<8>(lds32, o.w, lane, r, o.inv_w);
+      tile_to_lds<LMAX>(lds32, o.w, lane, r, o.inv_w);
       if (i + 1 < N) load(i + 1, tile);           // the next operand's column, same rows
       else if (next < tiles) load(0, next);       // or the first column of the next sub-tile
       wave_lds_fence();
@@ -417,16 +426,49 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_chain_kern
   }
 }
 
+template <int N, int LMAX>
+static ips_status launch_chain_nl(const ChainArgs<N>& a, int max_w, int64_t n_rows, uint32_t* bitmap32,
+                                  hipStream_t s) {
+  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  auto kern = fle_chain_kernel<N, LMAX>;
+  const int image_dwords = plane_tile_bytes(max_w) / 4;
+  const size_t lds = (size_t)kWavesPerBlock * image_dwords * 4;
+  // resident size: the dynamic image is not known to the occupancy cache of grid_for_tiles
+  static std::mutex mu;
+  static std::map<size_t, int> resident;  // per instantiation: image bytes -> workgroups per CU
+  int per_cu = 0;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = resident.find(lds);
+    if (it != resident.end()) per_cu = it->second;
+  }
+  if (per_cu == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kThreads, lds) != hipSuccess || per_cu <= 0)
+      per_cu = 2;
+    std::lock_guard<std::mutex> lk(mu);
+    resident[lds] = per_cu;
+  }
+  const int64_t want = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int64_t cap = (int64_t)device_cus() * per_cu * grid_mult();
+  const int64_t rounds = (want + cap - 1) / cap;
+  const int grid = (int)(want <= cap ? want : (want + rounds - 1) / rounds);
+  if (grid <= 0) return IPS_ERR_HIP;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, a, n_rows, bitmap32, image_dwords);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
 template <int N>
 static ips_status launch_chain_n(const ChainOp* ops, int64_t n_rows, uint32_t* bitmap32, hipStream_t s) {
   ChainArgs<N> a;
-  for (int i = 0; i < N; ++i) a.ops[i] = ops[i];
-  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
-  int grid = grid_for_tiles(reinterpret_cast<const void*>(fle_chain_kernel<N>), tiles);
-  if (grid <= 0) return IPS_ERR_HIP;
-  hipLaunchKernelGGL(fle_chain_kernel<N>, dim3(grid), dim3(kThreads), 0, s, a, n_rows, bitmap32);
-  IPS_HIP_TRY(hipGetLastError());
-  return IPS_OK;
+  int max_w = 1;
+  for (int i = 0; i < N; ++i) {
+    a.ops[i] = ops[i];
+    max_w = ops[i].w > max_w ? ops[i].w : max_w;
+  }
+  if (max_w <= 8) return launch_chain_nl<N, 2>(a, max_w, n_rows, bitmap32, s);
+  if (max_w <= 16) return launch_chain_nl<N, 4>(a, max_w, n_rows, bitmap32, s);
+  return launch_chain_nl<N, 8>(a, max_w, n_rows, bitmap32, s);
 }
 
 ips_status launch_program(const Program& prog, int64_t n_rows, uint32_t* bitmap32, hipStream_t s) {
