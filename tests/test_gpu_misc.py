@@ -643,6 +643,9 @@ def test_plain_scan(capi, O, type_name):
         lo, hi = np.sort(rng.choice(vals, 2))
         sel = (vals >= lo) & (vals <= hi)
         check(*capi.plain_scan(d_page, n, t, O.OP_GE, lo, op2=O.OP_LE, literal2=hi), sel)
+        # every row / no row selected: the index list is worked off in windows of 512 entries
+        check(*capi.plain_scan(d_page, n, t, O.OP_GE, vals.min()), np.ones(n, bool))
+        check(*capi.plain_scan(d_page, n, t, O.OP_LT, vals.min()), np.zeros(n, bool))
         lst = rng.choice(vals, min(5, n))
         check(*capi.plain_scan(d_page, n, t, O.OP_IN, lst), np.isin(vals, lst))
     with pytest.raises(capi.IpsError):
