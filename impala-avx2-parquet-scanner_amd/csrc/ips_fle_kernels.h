@@ -80,6 +80,35 @@ __device__ __forceinline__ uint32_t in_table_lookup(const uint32_t* table, const
 // Replaces EvalSimplePredicates + bitmap->skip-list + ReadValue(skip) of one column
 // (hdfs-parquet-scanner.cc:1837-1865, 1134-1181, 1006-1027; fle-encoding.h:8012-8066, 344-379).
 // ---------------------------------------------------------------------------------------------
+// LDS per wave.  Wide columns need the 9 KiB row tile (+ 1 KiB index list); a narrow column's plane
+// image and its parked lane-packed values are far smaller, and what the scan then buys with a
+// small footprint is OCCUPANCY: the fused scan is bound by VALU issue at 4 waves per SIMD (w = 8:
+// 194 VALU per sub-tile = 58 % of the SIMD's cycles at 62 % of the HBM roofline), and more resident
+// waves fill the gaps that LDS round trips and waitcnts leave (w = 8 @10 %: 82 -> 70 us with 4 KiB
+// per wave and 8 waves per SIMD).  The small layouts have no room for the dense compaction image
+// of 2048 dwords: beyond 512 selected rows they compact the lane-packed bytes / halfwords instead.
+#ifndef IPS_SCAN_SMALL_LDS
+#define IPS_SCAN_SMALL_LDS 1
+#endif
+#ifndef IPS_SCAN_SMALL_LDS_MAX_W
+#define IPS_SCAN_SMALL_LDS_MAX_W 8
+#endif
+#ifndef IPS_INDEX_PATH
+#define IPS_INDEX_PATH 1
+#endif
+template <int W, int MODE>
+struct ScanLds {
+  // (w = 9..16 with 6 KiB: the 96 registers that 5 waves per SIMD leave spill, and without spills
+  // the gain was 0-10 % at low selectivity against a 40 % loss above 25 %: left on the large layout)
+  static constexpr bool kSmall = IPS_SCAN_SMALL_LDS && IPS_INDEX_PATH && MODE != kScanInTable && W <= IPS_SCAN_SMALL_LDS_MAX_W;
+  static constexpr int kBody = !kSmall ? kRowTileBytes : W <= 8 ? 64 * packed_lane_stride(8) : 64 * packed_lane_stride(16);
+  static constexpr int kWaveBytes = kBody + kIndexListBytes;  // 4096 / 6144 / 10240
+  static_assert(plane_tile_bytes(kSmall ? (W <= 8 ? 8 : 16) : 32) <= kBody, "the plane image fits the body");
+  // waves per SIMD the register allocation is asked to allow (without the dense path's 32 value
+  // registers the narrow scans need 46-61 (w <= 8) and 79-96 (w <= 16) VGPRs)
+  static constexpr int kMinWaves = !kSmall ? IPS_MIN_WAVES_PER_EU : W <= 8 ? 8 : 5;
+};
+
 // first_tile / stride: the sub-tiles this wave takes (tile = first_tile, first_tile + stride, ...)
 template <int W, int MODE, int G>
 __device__ __forceinline__ void fle_scan_body(
@@ -88,13 +117,15 @@ __device__ __forceinline__ void fle_scan_body(
     typename GatherT<G>::type* __restrict__ batch_values, uint32_t* __restrict__ batch_counts,
     const typename GatherT<G>::type* __restrict__ dict, uint32_t dict_entries,
     int32_t* __restrict__ bad_index, int64_t first_tile, int64_t stride) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kScanWaveBytes / 4];
+  constexpr int kWB = ScanLds<W, MODE>::kWaveBytes;
+  constexpr bool kSmallLds = ScanLds<W, MODE>::kSmall;
+  __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kWB / 4];
   using GT = typename GatherT<G>::type;
   __shared__ GT dict_lds[DictLds<W, G>::kEntries];
   constexpr int L = (16 * W + kWave - 1) / kWave;
   const int lane = lane_id();
   const int wave = wave_id();
-  uint32_t* lds32 = lds_all + wave * (kScanWaveBytes / 4);
+  uint32_t* lds32 = lds_all + wave * (kWB / 4);
   if constexpr (DictLds<W, G>::kUse) {
     for (uint32_t i = threadIdx.x; i < dict_entries && i < (uint32_t)DictLds<W, G>::kEntries; i += kThreads)
       dict_lds[i] = dict[i];
@@ -246,9 +277,6 @@ __device__ __forceinline__ void fle_scan_body(
         tile = next;
         continue;
       }
-#ifndef IPS_INDEX_PATH
-#define IPS_INDEX_PATH 1
-#endif
       constexpr int R = LaneWidth<W>::R;
       constexpr bool kPacked = IPS_INDEX_PATH && !kInTable && R < 32;  // values stay lane-packed
 #ifndef IPS_QUADS
@@ -295,37 +323,14 @@ __device__ __forceinline__ void fle_scan_body(
         // phase A: one list entry (lane << 5 | row) per selected row.  Every lane runs the same
         // straight-line round -- lowest set bit, store under the exec mask, clear it -- until no
         // lane has a bit left; finished lanes keep clearing zero.
-        uint16_t* list = reinterpret_cast<uint16_t*>(lds8 + kRowTileBytes);
+        uint16_t* list = reinterpret_cast<uint16_t*>(lds8 + (kWB - kIndexListBytes));
 #ifndef IPS_PHASE_A_UNIFORM
 #define IPS_PHASE_A_UNIFORM 1  // trip count = the wave's largest popcount (one DPP max), no ballot per round
 #endif
 #ifndef IPS_PHASE_B_GROUP
 #define IPS_PHASE_B_GROUP 4    // rounds whose LDS reads are issued together
 #endif
-        if (IPS_ABLATE != 1) {
-          uint32_t m = bm;
-          uint16_t* slot = list + P;
-          const uint32_t lane5 = (uint32_t)lane << 5;
-          if (IPS_PHASE_A_UNIFORM) {
-            const uint32_t trips = wave_max(mine);  // scalar loop control: nothing waits for a ballot
-            for (uint32_t t = 0; t < trips; ++t) {
-              if (m != 0u) *slot = (uint16_t)(lane5 | (uint32_t)__builtin_ctz(m));
-              ++slot;
-              m &= m - 1u;
-            }
-          } else {
-            do {
-              if (m != 0u) *slot = (uint16_t)(lane5 | (uint32_t)__builtin_ctz(m));
-              ++slot;
-              m &= m - 1u;
-            } while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull);
-          }
-        }
-        wave_lds_fence();
-        // phase B: 64 entries per round, all lanes busy: entry -> LDS offset of the value -> slot.
-        // The rounds are taken in groups of four whose list reads, then value reads, are issued
-        // back to back (a round is two dependent LDS round trips; one after the other they were
-        // most of the phase's time).
+        const uint32_t lane5 = (uint32_t)lane << 5;
         int bad = 0;
         auto value_at = [&](uint32_t e) -> uint32_t {
           const uint32_t src = e >> 5, j = e & 31u;
@@ -360,22 +365,44 @@ __device__ __forceinline__ void fle_scan_body(
           }
         };
         constexpr uint32_t kGroup = IPS_PHASE_B_GROUP;
-        const uint32_t n_out = (IPS_ABLATE == 1 || IPS_ABLATE == 3) ? 0u : count;
-        for (uint32_t g0 = 0; g0 < n_out; g0 += kGroup * kWave) {  // wave-uniform
-          uint32_t e[kGroup], x[kGroup];
+        // phase B over the entries [0, n_win) of the list = rows win0.. of the sub-tile's selection
+        auto phase_b = [&](uint32_t win0, uint32_t n_win) {
+          for (uint32_t g0 = 0; g0 < n_win; g0 += kGroup * kWave) {  // wave-uniform
+            uint32_t e[kGroup], x[kGroup];
 #pragma unroll
-          for (uint32_t k = 0; k < kGroup; ++k) {
-            const uint32_t i = g0 + k * kWave + lane;
-            e[k] = list[i < n_out ? i : 0u];
+            for (uint32_t k = 0; k < kGroup; ++k) {
+              const uint32_t i = g0 + k * kWave + lane;
+              e[k] = list[i < n_win ? i : 0u];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < kGroup; ++k) x[k] = value_at(e[k]);
+#pragma unroll
+            for (uint32_t k = 0; k < kGroup; ++k) {
+              const uint32_t i = g0 + k * kWave + lane;
+              if (i < n_win) put(win0 + i, x[k]);
+            }
           }
-#pragma unroll
-          for (uint32_t k = 0; k < kGroup; ++k) x[k] = value_at(e[k]);
-#pragma unroll
-          for (uint32_t k = 0; k < kGroup; ++k) {
-            const uint32_t i = g0 + k * kWave + lane;
-            if (i < n_out) put(i, x[k]);
+        };
+        if (IPS_ABLATE != 1) {
+          uint32_t m = bm;
+          uint16_t* slot = list + P;
+          if (IPS_PHASE_A_UNIFORM) {
+            const uint32_t trips = wave_max(mine);  // scalar loop control: nothing waits for a ballot
+            for (uint32_t t = 0; t < trips; ++t) {
+              if (m != 0u) *slot = (uint16_t)(lane5 | (uint32_t)__builtin_ctz(m));
+              ++slot;
+              m &= m - 1u;
+            }
+          } else {
+            do {
+              if (m != 0u) *slot = (uint16_t)(lane5 | (uint32_t)__builtin_ctz(m));
+              ++slot;
+              m &= m - 1u;
+            } while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull);
           }
         }
+        wave_lds_fence();
+        phase_b(0u, (IPS_ABLATE == 1 || IPS_ABLATE == 3) ? 0u : count);
         if (G != 0 && bad && bad_index) *bad_index = 1;
       } else if (!IPS_INDEX_PATH && index_path) {
         // Round-1 sparse path (dev comparison, IPS_INDEX_PATH=0): each lane parks its 32 values in
@@ -413,6 +440,52 @@ __device__ __forceinline__ void fle_scan_body(
           }
         }
         if (G != 0 && bad && bad_index) *bad_index = 1;
+      } else if constexpr (kSmallLds) {
+        // Dense path of the small layouts (more than 512 selected rows): the lane-packed values
+        // (bytes for W <= 8, halfwords for W <= 16) are compacted as they are -- element e of the
+        // sub-tile's selection at byte e * EB of the region -- and leave four per lane and round.
+        constexpr int EB = R / 8;  // bytes per element: 1 / 2
+        uint32_t a[32];
+        planes_to_lanes<W>(p, a);
+        wave_lds_fence();  // all plane reads precede the overwrite of the same LDS region
+        uint8_t* img = reinterpret_cast<uint8_t*>(lds32);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+          const int pos = 31 - j;
+          const uint32_t field = a[pos % R] >> (R * (pos / R));
+          const uint32_t e = P + (uint32_t)__builtin_popcount(bm & ((1u << j) - 1u));
+          if ((bm >> j) & 1u) {
+            if (EB == 1) img[e] = (uint8_t)field;
+            else *reinterpret_cast<uint16_t*>(img + 2 * e) = (uint16_t)field;
+          }
+        }
+        wave_lds_fence();
+        int bad = 0;
+        for (uint32_t e0 = 4u * lane; e0 < count; e0 += 4u * kWave) {
+          uint32_t x[4];
+          if (EB == 1) {
+            const uint32_t w4 = *reinterpret_cast<const uint32_t*>(img + e0);
+            x[0] = w4 & 0xFFu; x[1] = (w4 >> 8) & 0xFFu; x[2] = (w4 >> 16) & 0xFFu; x[3] = w4 >> 24;
+          } else {
+            const uint32_t lo = *reinterpret_cast<const uint32_t*>(img + 2 * e0);
+            const uint32_t hi = *reinterpret_cast<const uint32_t*>(img + 2 * e0 + 4);
+            x[0] = lo & 0xFFFFu; x[1] = lo >> 16; x[2] = hi & 0xFFFFu; x[3] = hi >> 16;
+          }
+          if (G == 0 && e0 + 3 < count) {
+            const u32x4 t = {x[0], x[1], x[2], x[3]};
+            *reinterpret_cast<u32x4*>(reinterpret_cast<uint32_t*>(dst) + e0) = t;  // batch slots are 8 KiB aligned
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (e0 + k < count) {
+                if (G == 0) dst[e0 + k] = (GT)x[k];
+                else if (x[k] < dict_entries) dst[e0 + k] = lookup(x[k]);
+                else bad = 1;
+              }
+            }
+          }
+        }
+        if (G != 0 && bad && bad_index) *bad_index = 1;
       } else {
         if (!kInTable) planes_to_values<W>(p, v);
         wave_lds_fence();
@@ -437,7 +510,7 @@ __device__ __forceinline__ void fle_scan_body(
 }
 
 template <int W, int MODE, int G>
-__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_kernel(
+__global__ __launch_bounds__(kThreads, (ScanLds<W, MODE>::kMinWaves)) void fle_scan_kernel(
     const uint64_t* __restrict__ enc, int64_t n_rows, PredArgs args,
     uint32_t* __restrict__ bitmap32, const uint32_t* __restrict__ given_bitmap32,
     typename GatherT<G>::type* __restrict__ batch_values, uint32_t* __restrict__ batch_counts,
@@ -468,7 +541,7 @@ struct PageBatch { PageScan pages[kPagesPerLaunch]; };
 // constant-address-space kernarg pointer -- indexing the by-value argument with blockIdx.y would
 // make the compiler copy all of it to scratch.
 template <int W>
-__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_scan_pages_kernel(
+__global__ __launch_bounds__(kThreads, (ScanLds<W, kScanPredicate>::kMinWaves)) void fle_scan_pages_kernel(
     PageBatch batch, PredArgs args) {
 #if defined(__HIP_DEVICE_COMPILE__)
   (void)batch;
