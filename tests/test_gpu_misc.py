@@ -93,6 +93,36 @@ def test_dict_pred_decode_scan(capi, O, type_name):
     dd.close()
 
 
+@pytest.mark.parametrize("type_name", ["T_INT32", "T_INT64", "T_DOUBLE"])
+@pytest.mark.parametrize("distinct", [5, 60, 256])
+def test_narrow_dictionary_scan_every_selectivity(capi, O, type_name, distinct):
+    """Dictionaries of up to 256 entries (code widths 3 / 6 / 8: the scan's 4 KiB LDS layout) with
+    4- and 8-byte entries: fused scan + gather and select from 0 % to 100 % selectivity, i.e. the
+    gather path, the index list and the packed dense path, over ragged multi-batch columns."""
+    t = getattr(O, type_name)
+    rng = np.random.default_rng(900 + t + distinct)
+    for n in (257, 2047, 2049, 20011):
+        vals = make_dict_column(O, t, rng, n, distinct)
+        d, dict_page, codes = O.dict_build(vals, t)
+        data = O.dict_write_data(codes, len(d))
+        bw, blocks = page_blocks(data)
+        dd = capi.Dict(dict_page, t)
+        enc = dev_words(blocks)
+        for q in (0.0, 0.02, 0.2, 0.3, 0.6, 1.0):
+            lit = d[min(len(d) - 1, int(q * len(d)))]
+            for op in ((O.OP_LT, O.OP_GE) if q < 1.0 else (O.OP_LE,)):
+                ref = O.dict_pred(d, t, data, n, op, lit)
+                bitmap, bvals, counts = dd.scan(enc, n, bw, op, lit)
+                assert np.array_equal(words(bitmap), ref), (type_name, distinct, n, q, op)
+                dense = capi.batches_compact(bvals, counts, n).cpu().numpy().astype(O.NP_TYPES[t])
+                assert np.array_equal(dense, vals[bits_of(ref, n)]), (type_name, distinct, n, q, op)
+                sv, sc = dd.select(enc, n, bw, bitmap)
+                assert torch.equal(sc, counts)
+                dense2 = capi.batches_compact(sv, sc, n).cpu().numpy().astype(O.NP_TYPES[t])
+                assert np.array_equal(dense2, dense)
+        dd.close()
+
+
 def test_dict_bad_index_flag(capi, O):
     """A code >= num_entries: the reference's GetValue returns false (dict-encoding.h:316)."""
     d = np.arange(5, dtype=np.int32)
