@@ -309,35 +309,49 @@ __device__ __forceinline__ u64 extract64(u64 src, u64 mask, const uint8_t* __res
   return out;
 }
 
-constexpr int kSegWords = kRankWordsPerWave + 2;  // a wave's output segment: <= 65536 bits + misalignment
+// Like expand_kernel, a workgroup takes a quarter tile (four waves of 256 words): several
+// generations of workgroups per CU, 2 KiB of LDS segment per wave instead of 8.
+constexpr int kSegWords = kExpWordsPerWave + 2;  // a wave's output segment: <= 16384 bits + misalignment
 
 template <int MASK, int SRC>
 __global__ __launch_bounds__(kRankThreads) void compress_kernel(
     const u64* __restrict__ mask, const u64* __restrict__ src, int64_t n_rows,
-    const uint32_t* __restrict__ tile_counts, u64* __restrict__ out, int64_t* __restrict__ n_out) {
+    const uint32_t* __restrict__ tile_counts, int64_t tiles, u64* __restrict__ out,
+    int64_t* __restrict__ n_out) {
   __shared__ uint8_t lut[256];
-  __shared__ u64 part[kRankThreads / kWave];
-  __shared__ uint32_t wave_tot[kRankThreads / kWave];
-  __shared__ __attribute__((aligned(16))) u64 seg_all[(kRankThreads / kWave) * kSegWords];
+  __shared__ u64 part[kRankWaves];
+  __shared__ uint32_t wave_tot[kRankWaves];
+  __shared__ __attribute__((aligned(16))) u64 seg_all[kRankWaves * kSegWords];
   const int lane = lane_id();
   const int wave = wave_id();
   const int64_t n_words = (n_rows + 63) / 64;
   extract_lut_init(lut);
   u64* seg = seg_all + wave * kSegWords;
   for (int i = lane; i < kSegWords; i += kWave) seg[i] = 0ull;
-  u64 before = 0;
-  for (int64_t i = threadIdx.x; i < (int64_t)blockIdx.x; i += kRankThreads) before += tile_counts[i];
-  for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
-  if (lane == 0) part[wave] = before;
-
-  const int64_t first = (int64_t)blockIdx.x * kRankWordsPerTile + wave * kRankWordsPerWave;
-  u64 m[kRankRounds][2], sv[kRankRounds][2];
-  load_root<MASK, kRankRounds>(mask, first, n_words, n_rows, lane, m);
-  load_root<SRC, kRankRounds>(src, first, n_words, n_rows, lane, sv);
-  uint32_t excl[kRankRounds];
+  const int64_t first = (int64_t)blockIdx.x * kExpWordsPerBlock + wave * kExpWordsPerWave;
+  const bool whole = (first + kExpWordsPerWave) * 64 <= n_rows;  // wave-uniform
+  u64 m[kExpRounds][2], sv[kExpRounds][2];
+  if (whole) {
+    load_root_whole<MASK, kExpRounds>(mask, first, lane, m);
+    load_root_whole<SRC, kExpRounds>(src, first, lane, sv);
+  } else {
+    load_root<MASK, kExpRounds>(mask, first, n_words, n_rows, lane, m);
+    load_root<SRC, kExpRounds>(src, first, n_words, n_rows, lane, sv);
+  }
+  // block base, as in expand_kernel
+  const int64_t tile = (int64_t)blockIdx.x / kExpBlocksPerTile;
+  const int part_waves = (int)(blockIdx.x % kExpBlocksPerTile) * (kRankWaves / kExpBlocksPerTile);
+  uint32_t before = 0;
+  for (int64_t i = threadIdx.x; i < tile; i += kRankThreads) before += tile_counts[i];
+  if ((int)threadIdx.x < part_waves) before += tile_counts[tiles + tile * kRankWaves + threadIdx.x];
+  {
+    const uint32_t lo = wave_sum(before & 0xFFFFu), hi = wave_sum(before >> 16);
+    if (lane == 0) part[wave] = (u64)lo + ((u64)hi << 16);
+  }
+  uint32_t excl[kExpRounds];
   uint32_t run = 0;
 #pragma unroll
-  for (int r = 0; r < kRankRounds; ++r) {
+  for (int r = 0; r < kExpRounds; ++r) {
     const uint32_t c = (uint32_t)(__builtin_popcountll(m[r][0]) + __builtin_popcountll(m[r][1]));
     const uint32_t incl = wave_inclusive_scan(c);
     excl[r] = run + incl - c;
@@ -348,11 +362,11 @@ __global__ __launch_bounds__(kRankThreads) void compress_kernel(
   u64 base = part[0] + part[1] + part[2] + part[3];
   for (int w = 0; w < wave; ++w) base += wave_tot[w];
   if (n_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == kRankThreads - 1)
-    *n_out = (int64_t)(base + run);  // last wave of the last tile: popcount(mask)
+    *n_out = (int64_t)(base + run);  // last wave of the last block: popcount(mask)
 
   const uint32_t lead = (uint32_t)(base & 63);  // the segment starts inside global word base >> 6
 #pragma unroll
-  for (int r = 0; r < kRankRounds; ++r) {
+  for (int r = 0; r < kExpRounds; ++r) {
     uint32_t o = lead + excl[r];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -385,12 +399,14 @@ __global__ __launch_bounds__(kRankThreads) void compress_kernel(
 }
 
 template <int MASK>
-static void launch_compress_src(int src_kind, dim3 grid, hipStream_t s, const u64* mask, const u64* src,
+static void launch_compress_src(int src_kind, int64_t tiles, hipStream_t s, const u64* mask, const u64* src,
                                 int64_t n_rows, const uint32_t* counts, u64* out, int64_t* n_out) {
+  const int64_t n_words = (n_rows + 63) / 64;
+  const dim3 grid((unsigned)((n_words + kExpWordsPerBlock - 1) / kExpWordsPerBlock));
   if (src_kind == kRootLevels1)
-    hipLaunchKernelGGL((compress_kernel<MASK, kRootLevels1>), grid, dim3(kRankThreads), 0, s, mask, src, n_rows, counts, out, n_out);
+    hipLaunchKernelGGL((compress_kernel<MASK, kRootLevels1>), grid, dim3(kRankThreads), 0, s, mask, src, n_rows, counts, tiles, out, n_out);
   else
-    hipLaunchKernelGGL((compress_kernel<MASK, kRootBitmap>), grid, dim3(kRankThreads), 0, s, mask, src, n_rows, counts, out, n_out);
+    hipLaunchKernelGGL((compress_kernel<MASK, kRootBitmap>), grid, dim3(kRankThreads), 0, s, mask, src, n_rows, counts, tiles, out, n_out);
 }
 
 // mask_kind / src_kind: kRootBitmap or kRootLevels1 (width-1 definition levels used as NOT-NULL bits)
@@ -408,10 +424,10 @@ ips_status launch_compress(int mask_kind, const uint64_t* mask, int src_kind, co
   const dim3 grid((unsigned)tiles);
   if (mask_kind == kRootLevels1) {
     hipLaunchKernelGGL((rank_tile_counts_kernel<kRootLevels1, true>), grid, dim3(kRankThreads), 0, s, mk, n_rows, tile_counts, o);
-    launch_compress_src<kRootLevels1>(src_kind, grid, s, mk, sr, n_rows, tile_counts, o, n_out);
+    launch_compress_src<kRootLevels1>(src_kind, tiles, s, mk, sr, n_rows, tile_counts, o, n_out);
   } else {
     hipLaunchKernelGGL((rank_tile_counts_kernel<kRootBitmap, true>), grid, dim3(kRankThreads), 0, s, mk, n_rows, tile_counts, o);
-    launch_compress_src<kRootBitmap>(src_kind, grid, s, mk, sr, n_rows, tile_counts, o, n_out);
+    launch_compress_src<kRootBitmap>(src_kind, tiles, s, mk, sr, n_rows, tile_counts, o, n_out);
   }
   IPS_HIP_TRY(hipGetLastError());
   return IPS_OK;
