@@ -100,13 +100,18 @@ template <int W, int MODE>
 struct ScanLds {
   // (w = 9..16 with 6 KiB: the 96 registers that 5 waves per SIMD leave spill, and without spills
   // the gain was 0-10 % at low selectivity against a 40 % loss above 25 %: left on the large layout)
-  static constexpr bool kSmall = IPS_SCAN_SMALL_LDS && IPS_INDEX_PATH && MODE != kScanInTable && W <= IPS_SCAN_SMALL_LDS_MAX_W;
+  // IN-list scans of w = 9..16 (dictionary codes, a handful of rows selected) do take the small
+  // layout, WITHOUT a dense path: beyond 512 selected rows of a sub-tile they work the index list
+  // off in windows of 512 (kWindowed) -- slow there, but their registers then fit 5 waves per SIMD.
+  static constexpr bool kWindowed = IPS_SCAN_SMALL_LDS && IPS_INDEX_PATH && MODE == kScanInList && W > IPS_SCAN_SMALL_LDS_MAX_W && W <= 16;
+  static constexpr bool kSmall = IPS_SCAN_SMALL_LDS && IPS_INDEX_PATH && MODE != kScanInTable &&
+                                 (W <= IPS_SCAN_SMALL_LDS_MAX_W || kWindowed);
   static constexpr int kBody = !kSmall ? kRowTileBytes : W <= 8 ? 64 * packed_lane_stride(8) : 64 * packed_lane_stride(16);
   static constexpr int kWaveBytes = kBody + kIndexListBytes;  // 4096 / 6144 / 10240
   static_assert(plane_tile_bytes(kSmall ? (W <= 8 ? 8 : 16) : 32) <= kBody, "the plane image fits the body");
   // waves per SIMD the register allocation is asked to allow (without the dense path's 32 value
   // registers the narrow scans need 46-61 (w <= 8) and 79-96 (w <= 16) VGPRs)
-  static constexpr int kMinWaves = !kSmall ? IPS_MIN_WAVES_PER_EU : W <= 8 ? 8 : 5;
+  static constexpr int kMinWaves = !kSmall ? IPS_MIN_WAVES_PER_EU : W <= IPS_SCAN_SMALL_LDS_MAX_W ? 8 : 5;
 };
 
 // first_tile / stride: the sub-tiles this wave takes (tile = first_tile, first_tile + stride, ...)
@@ -119,6 +124,7 @@ __device__ __forceinline__ void fle_scan_body(
     int32_t* __restrict__ bad_index, int64_t first_tile, int64_t stride) {
   constexpr int kWB = ScanLds<W, MODE>::kWaveBytes;
   constexpr bool kSmallLds = ScanLds<W, MODE>::kSmall;
+  constexpr bool kWindowed = ScanLds<W, MODE>::kWindowed;
   __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kWB / 4];
   using GT = typename GatherT<G>::type;
   __shared__ GT dict_lds[DictLds<W, G>::kEntries];
@@ -287,7 +293,7 @@ __device__ __forceinline__ void fle_scan_body(
 #define IPS_QUADS16 1  // w=16 / 12 / 10 LT @10 %: 134 -> 117 / 127 -> 111 / 114 -> 100 us
 #endif
       constexpr bool kQuads16 = IPS_QUADS16 && kPacked && R == 16;
-      const bool index_path = IPS_INDEX_PATH ? count <= (uint32_t)kIndexListMax
+      const bool index_path = IPS_INDEX_PATH ? (kWindowed || count <= (uint32_t)kIndexListMax)
                                              : __builtin_amdgcn_ballot_w64(mine > kSparseLaneMax) == 0ull;
       if (IPS_INDEX_PATH && index_path) {
         // Index-list path (up to 25 % selectivity).  The lane parks its 32 values in LDS -- as
@@ -383,26 +389,44 @@ __device__ __forceinline__ void fle_scan_body(
             }
           }
         };
-        if (IPS_ABLATE != 1) {
-          uint32_t m = bm;
-          uint16_t* slot = list + P;
-          if (IPS_PHASE_A_UNIFORM) {
-            const uint32_t trips = wave_max(mine);  // scalar loop control: nothing waits for a ballot
-            for (uint32_t t = 0; t < trips; ++t) {
-              if (m != 0u) *slot = (uint16_t)(lane5 | (uint32_t)__builtin_ctz(m));
-              ++slot;
-              m &= m - 1u;
+        if (!kWindowed || count <= (uint32_t)kIndexListMax) {  // wave-uniform: the whole list fits
+          if (IPS_ABLATE != 1) {
+            uint32_t m = bm;
+            uint16_t* slot = list + P;
+            if (IPS_PHASE_A_UNIFORM) {
+              const uint32_t trips = wave_max(mine);  // scalar loop control: nothing waits for a ballot
+              for (uint32_t t = 0; t < trips; ++t) {
+                if (m != 0u) *slot = (uint16_t)(lane5 | (uint32_t)__builtin_ctz(m));
+                ++slot;
+                m &= m - 1u;
+              }
+            } else {
+              do {
+                if (m != 0u) *slot = (uint16_t)(lane5 | (uint32_t)__builtin_ctz(m));
+                ++slot;
+                m &= m - 1u;
+              } while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull);
             }
-          } else {
-            do {
-              if (m != 0u) *slot = (uint16_t)(lane5 | (uint32_t)__builtin_ctz(m));
-              ++slot;
-              m &= m - 1u;
-            } while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull);
+          }
+          wave_lds_fence();
+          phase_b(0u, (IPS_ABLATE == 1 || IPS_ABLATE == 3) ? 0u : count);
+        } else {
+          // windows of 512 entries, every lane resuming where it stopped
+          uint32_t m = bm, pos = P;
+          for (uint32_t win0 = 0; win0 < count; win0 += (uint32_t)kIndexListMax) {
+            const uint32_t win1 = win0 + (uint32_t)kIndexListMax;
+            while (__builtin_amdgcn_ballot_w64(m != 0u && pos < win1) != 0ull) {
+              if (m != 0u && pos < win1) {
+                list[pos - win0] = (uint16_t)(lane5 | (uint32_t)__builtin_ctz(m));
+                m &= m - 1u;
+                ++pos;
+              }
+            }
+            wave_lds_fence();
+            phase_b(win0, count - win0 < (uint32_t)kIndexListMax ? count - win0 : (uint32_t)kIndexListMax);
+            wave_lds_fence();  // the list is rewritten by the next window
           }
         }
-        wave_lds_fence();
-        phase_b(0u, (IPS_ABLATE == 1 || IPS_ABLATE == 3) ? 0u : count);
         if (G != 0 && bad && bad_index) *bad_index = 1;
       } else if (!IPS_INDEX_PATH && index_path) {
         // Round-1 sparse path (dev comparison, IPS_INDEX_PATH=0): each lane parks its 32 values in
@@ -440,7 +464,7 @@ __device__ __forceinline__ void fle_scan_body(
           }
         }
         if (G != 0 && bad && bad_index) *bad_index = 1;
-      } else if constexpr (kSmallLds) {
+      } else if constexpr (kSmallLds && !kWindowed) {
         // Dense path of the small layouts (more than 512 selected rows): the lane-packed values
         // (bytes for W <= 8, halfwords for W <= 16) are compacted as they are -- element e of the
         // sub-tile's selection at byte e * EB of the region -- and leave four per lane and round.

@@ -91,6 +91,24 @@ def test_in_list_lengths(capi, O, bw):
         check_batches(bvals, counts, n, O.fle_select(ref_enc, n, bw, ref), capi)
 
 
+@pytest.mark.parametrize("bw", [9, 12, 16])
+def test_in_list_scan_dense_selection(capi, O, bw):
+    """A short IN list that selects most rows of a w = 9..16 column (skewed values): the fused scan
+    works its index list off in several windows of 512 entries per sub-tile."""
+    rng = np.random.default_rng(950 + bw)
+    for n in (2048, 2049, 30011):
+        hot = rng.choice(1 << bw, 3, replace=False)
+        vals = np.where(rng.random(n) < 0.7, hot[rng.integers(0, 3, n)], rng.integers(0, 1 << bw, n)).astype(np.uint32)
+        ref_enc = O.fle_encode(vals, bw)
+        enc = enc_to_dev(ref_enc)
+        lst = [int(x) for x in hot] + [int(rng.integers(0, 1 << bw)), int(vals[0])]
+        ref = O.fle_pred(ref_enc, n, bw, O.OP_IN, lst)
+        bitmap, bvals, counts = capi.fle_scan(enc, n, bw, O.OP_IN, lst)
+        assert np.array_equal(words(bitmap), ref), (bw, n)
+        assert counts.cpu().numpy().max() > 1200 or n < 2049
+        check_batches(bvals, counts, n, O.fle_select(ref_enc, n, bw, ref), capi)
+
+
 def check_batches(bvals, counts, n, expect_dense, capi):
     counts_h = counts.cpu().numpy()
     b_h = bvals.cpu().numpy().view(np.uint32)
