@@ -99,9 +99,45 @@ __device__ __forceinline__ u32x4 stream_load(const u32x4* p) {
 #define IPS_STREAM_STORE16(p, v) __builtin_nontemporal_store((v), reinterpret_cast<u32x4*>(p))
 #endif
 
+// The sub-tile is read through a BUFFER resource that spans exactly its bytes inside the encoded
+// buffer (base = first word of the sub-tile, num_records = min(256 W, bytes left)): the hardware's
+// range check returns zeros for every dword outside it, so the last, partial sub-tile of a column,
+// a sub-tile past the end and the lanes beyond chunk 16 W all take the same instructions as a
+// whole sub-tile.  (The first version branched to a per-chunk bounds path for the last sub-tile:
+// never executed twice, but its 64-bit addresses and conditions cost every FLE kernel about 34
+// VGPRs of allocation -- fle_scan_kernel<32>: 150 -> 116 = 4 waves per SIMD instead of 3.)
+#ifndef IPS_BUFFER_LOADS
+#define IPS_BUFFER_LOADS 1
+#endif
+constexpr unsigned kBufferRsrcDword3 = 0x00020000u;  // gfx9 family: DATA_FORMAT_32, raw (unswizzled) buffer
+
+template <bool NT = true>
+__device__ __forceinline__ u32x4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset) {
+#ifdef IPS_NO_NT_LOADS
+  return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_offset, 0, 0);
+#else
+  return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_offset, 0, NT ? 2 : 0);  // aux bit 1: nt
+#endif
+}
+
+// resource over the bytes of sub-tile 'tile' that exist (none: an empty resource, every load 0)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const uint64_t* __restrict__ enc, int64_t tile,
+                                                            int w, int64_t total_words) {
+  const int64_t w0 = tile * (int64_t)(kBlocksPerTile * w);
+  int64_t left = total_words - w0;  // words of the buffer from the sub-tile's first word on
+  left = left < 0 ? 0 : (left > kBlocksPerTile * w ? kBlocksPerTile * w : left);
+  const uint64_t* base = left > 0 ? enc + w0 : enc;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(base), 0, (int)(left * 8), kBufferRsrcDword3);
+}
+
 template <int MAXLOADS, bool NT = true>
 __device__ __forceinline__ void tile_load(const uint64_t* __restrict__ enc, int64_t tile, int w,
                                           int64_t total_words, int lane, u32x4 (&r)[MAXLOADS]) {
+#if IPS_BUFFER_LOADS
+  const __amdgpu_buffer_rsrc_t rsrc = tile_rsrc(enc, tile, w, total_words);
+#pragma unroll
+  for (int i = 0; i < MAXLOADS; ++i) r[i] = buffer_load16<NT>(rsrc, (uint32_t)(i * kWave + lane) * 16u);
+#else
   const int64_t w0 = tile * (int64_t)(kBlocksPerTile * w);
   const int chunks = 16 * w;
   const uint64_t* base = enc + w0;
@@ -128,6 +164,7 @@ __device__ __forceinline__ void tile_load(const uint64_t* __restrict__ enc, int6
       r[i] = v;
     }
   }
+#endif
 }
 
 // Late materialisation against a given bitmap touches only the blocks that hold a selected row --
@@ -140,6 +177,18 @@ template <int MAXLOADS, int W>
 __device__ __forceinline__ void tile_load_needed(const uint64_t* __restrict__ enc, int64_t tile,
                                                  int64_t total_words, int lane,
                                                  uint64_t need_blocks, u32x4 (&r)[MAXLOADS]) {
+#if IPS_BUFFER_LOADS
+  const __amdgpu_buffer_rsrc_t rsrc = tile_rsrc(enc, tile, W, total_words);
+#pragma unroll
+  for (int i = 0; i < MAXLOADS; ++i) {
+    const int c = i * kWave + lane;
+    if (c < 16 * W) {
+      const int b0 = (2 * c) / W, b1 = (2 * c + 1) / W;
+      if (((need_blocks >> (2 * b0)) | (need_blocks >> (2 * b1))) & 1ull)
+        r[i] = buffer_load16<true>(rsrc, (uint32_t)c * 16u);
+    }
+  }
+#else
   const int64_t w0 = tile * (int64_t)(kBlocksPerTile * W);
   if (w0 + kBlocksPerTile * W > total_words) {  // last, partial sub-tile: the guarded plain path
     tile_load<MAXLOADS, true>(enc, tile, W, total_words, lane, r);
@@ -155,6 +204,7 @@ __device__ __forceinline__ void tile_load_needed(const uint64_t* __restrict__ en
         r[i] = stream_load<true>(reinterpret_cast<const u32x4*>(base + 2 * c));
     }
   }
+#endif
 }
 
 // ---- VGPR -> LDS (odd word stride per block) ------------------------------------------------
