@@ -685,6 +685,14 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_ear
 
   // half = 1: words 16..31 of every block (planes 31..16), half = 0: words 0..15
   auto load_half = [&](int64_t tile, int half, u32x4 (&r)[4]) {
+#if IPS_BUFFER_LOADS
+    const __amdgpu_buffer_rsrc_t rsrc = tile_rsrc(enc, tile, W, total_words);  // range-checked by the hardware
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = i * kWave + lane;                  // 256 chunks of 16 bytes per half tile
+      r[i] = buffer_load16<true>(rsrc, (uint32_t)(((ch >> 3) * W + half * 16 + (ch & 7) * 2) * 8));
+    }
+#else
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ch = i * kWave + lane;                  // 256 chunks of 16 bytes per half tile
@@ -693,6 +701,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_ear
       if (word + 1 < total_words) v = stream_load(reinterpret_cast<const u32x4*>(enc + word));
       r[i] = v;                                         // whole blocks only: words come in pairs
     }
+#endif
   };
   auto stage_half = [&](int half, const u32x4 (&r)[4]) {
 #pragma unroll
