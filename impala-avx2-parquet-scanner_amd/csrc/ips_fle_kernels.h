@@ -790,18 +790,39 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_ear
 // OW = bytes per stored value (1, 2, 4) when G == 0; with G != 0 every code is looked up in the
 // dictionary and the G-byte entry is stored (DictDecoder::GetValue, dict-encoding.h:310-319).
 // ---------------------------------------------------------------------------------------------
+// Dictionary columns of up to 16 bits (codes -> entries) take the PACKED path:
+// the lane parks its 32 values lane-packed (8 registers of four bytes / 16 of two halfwords: the
+// transposition stops where the values are bytes / halfwords), and the output is produced in
+// 16-byte pieces of four consecutive rows: piece P = 64 k + lane of the sub-tile is rows 4q..4q+3 of
+// source lane s = P / 8, q = lane % 8 -- one field of four neighbouring parked registers, i.e. one
+// ds_read_b128 and four bit-field extracts (8-byte entries: pieces of two rows, one ds_read_b64, so
+// that every store instruction still writes 1 KiB of consecutive output).  Against the row tile of the general path (every value
+// unpacked to a dword, 32 dword writes + reads per lane): 3 / 5 KiB of LDS per wave instead of 9
+// and about half the VALU (dictionary decode D = 4096, w = 12: 525 -> 2xx per sub-tile).
+#ifndef IPS_DECODE_PACKED
+#define IPS_DECODE_PACKED 1
+#endif
+template <int W, int OW, int G>
+struct DecodeLds {
+  static constexpr bool kPacked = IPS_DECODE_PACKED && W <= 16 && G != 0;  // (to plain dwords: no gain, write-bound)
+  static constexpr int kWaveBytes = !kPacked ? kRowTileBytes : 64 * packed_lane_stride(W <= 8 ? 8 : 16);
+  static_assert(!kPacked || plane_tile_bytes(W) <= kWaveBytes, "the plane image fits");
+};
+
 template <int W, int OW, int G>
 __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_decode_kernel(
     const uint64_t* __restrict__ enc, int64_t n_rows, void* __restrict__ out,
     const typename GatherT<G>::type* __restrict__ dict, uint32_t dict_entries,
     int32_t* __restrict__ bad_index) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kRowTileBytes / 4];
+  constexpr bool kPackedOut = DecodeLds<W, OW, G>::kPacked;
+  constexpr int kDecWaveBytes = DecodeLds<W, OW, G>::kWaveBytes;
+  __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kDecWaveBytes / 4];
   using GT = typename GatherT<G>::type;
   __shared__ GT dict_lds[DictLds<W, G, kDecodeDictLdsBytes>::kEntries];
   constexpr int L = (16 * W + kWave - 1) / kWave;
   const int lane = lane_id();
   const int wave = wave_id();
-  uint32_t* lds32 = lds_all + wave * (kRowTileBytes / 4);
+  uint32_t* lds32 = lds_all + wave * (kDecWaveBytes / 4);
   if constexpr (DictLds<W, G, kDecodeDictLdsBytes>::kUse) {
     for (uint32_t i = threadIdx.x; i < dict_entries && i < (uint32_t)DictLds<W, G, kDecodeDictLdsBytes>::kEntries; i += kThreads)
       dict_lds[i] = dict[i];
@@ -827,13 +848,94 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_decode_ker
 
     uint32_t p[W];
     planes_from_lds<W>(lds32, lane, p);
+    const int64_t row_base = tile * kRowsPerTile;
+    if constexpr (kPackedOut) {
+      constexpr int R = LaneWidth<W>::R;             // 8 or 16 parked registers per lane
+      constexpr int kStride = packed_lane_stride(R);  // 48 / 80 bytes
+      uint32_t a[32];
+      planes_to_lanes<W>(p, a);
+      wave_lds_fence();  // all plane reads precede the overwrite of the same LDS region
+      uint8_t* lds8 = reinterpret_cast<uint8_t*>(lds32);
+#pragma unroll
+      for (int i = 0; i < R / 4; ++i) {
+        const u32x4 t = {a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]};
+        *reinterpret_cast<u32x4*>(lds8 + lane * kStride + 16 * i) = t;
+      }
+      wave_lds_fence();
+      constexpr uint32_t kMask = (1u << R) - 1u;
+      int bad = 0;
+      GT* dst_all = reinterpret_cast<GT*>(out);
+      if constexpr (sizeof(GT) == 4) {
+        // rows 4q..4q+3 of a lane sit at bit positions pos = 31-4q .. 28-4q: field pos / R of the
+        // registers pos % R, four neighbouring registers of one aligned group
+        const int q = lane & 7;
+        const int pos0 = 31 - 4 * q;
+        const int grp = (pos0 % R) / 4;     // registers 4 grp .. 4 grp + 3
+        const uint32_t fsh = (uint32_t)(R * (pos0 / R));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int src = 8 * k + (lane >> 3);
+          const u32x4 t = *reinterpret_cast<const u32x4*>(lds8 + src * kStride + 16 * grp);
+          // descending registers = ascending rows
+          const uint32_t x[4] = {(t.w >> fsh) & kMask, (t.z >> fsh) & kMask, (t.y >> fsh) & kMask, (t.x >> fsh) & kMask};
+          const int64_t row = row_base + 4 * (64 * k + lane);
+          const int64_t valid = n_rows - row;
+          GT y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = e < valid;
+            if (ok && x[e] >= dict_entries) bad = 1;
+            y[e] = (ok && x[e] < dict_entries) ? lookup(x[e]) : GT(0);
+          }
+          if (valid >= 4) {
+            const u32x4 o = {(uint32_t)y[0], (uint32_t)y[1], (uint32_t)y[2], (uint32_t)y[3]};
+            IPS_STREAM_STORE16(dst_all + row, o);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (e < valid && x[e] < dict_entries) dst_all[row + e] = y[e];
+          }
+        }
+      } else {
+        // 8-byte entries: rows 2u, 2u+1 of a lane (u = lane % 16): positions 31-2u, 30-2u = the
+        // same field of two neighbouring registers
+        const int u = lane & 15;
+        const int pos0 = 31 - 2 * u;
+        const int reg_lo = (pos0 - 1) % R;  // even register of the pair
+        const uint32_t fsh = (uint32_t)(R * (pos0 / R));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int src = 4 * k + (lane >> 4);
+          const u32x2 t = *reinterpret_cast<const u32x2*>(lds8 + src * kStride + 4 * reg_lo);
+          const uint32_t x[2] = {(t.y >> fsh) & kMask, (t.x >> fsh) & kMask};
+          const int64_t row = row_base + 2 * (64 * k + lane);
+          const int64_t valid = n_rows - row;
+          GT y[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const bool ok = e < valid;
+            if (ok && x[e] >= dict_entries) bad = 1;
+            y[e] = (ok && x[e] < dict_entries) ? lookup(x[e]) : GT(0);
+          }
+          if (valid >= 2) {
+            const u32x4 o = {(uint32_t)y[0], (uint32_t)((uint64_t)y[0] >> 32), (uint32_t)y[1], (uint32_t)((uint64_t)y[1] >> 32)};
+            IPS_STREAM_STORE16(dst_all + row, o);
+          } else if (valid == 1 && x[0] < dict_entries) {
+            dst_all[row] = y[0];
+          }
+        }
+      }
+      if (G != 0 && bad && bad_index) *bad_index = 1;
+      wave_lds_fence();  // LDS region is reused by the next sub-tile
+      tile = next;
+      continue;
+    }
     uint32_t v[32];
     planes_to_values<W>(p, v);
     wave_lds_fence();
     values_to_row_tile(lds32, lane, v);
     wave_lds_fence();
 
-    const int64_t row_base = tile * kRowsPerTile;
     if (G != 0) {
       typename GatherT<G>::type* dst = reinterpret_cast<typename GatherT<G>::type*>(out);
       int bad = 0;
