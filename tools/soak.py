@@ -6,7 +6,7 @@ import numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import __graft_entry__ as entry
 ips = entry.load_package(); capi = ips.capi; O = entry.load_oracle()
-rng = np.random.default_rng(20261004)
+rng = np.random.default_rng(int(os.environ.get("IPS_SOAK_SEED", "20261004")))
 def words(t): return t.cpu().numpy().view(np.uint64)
 bad = 0
 for it in range(400):
