@@ -107,6 +107,9 @@ struct Reader {
     *last_id = *id;
     return ok;
   }
+  void skip_element(int type) {
+    if (type == T_TRUE || type == T_FALSE) byte(); else skip(type);
+  }
   void skip(int type) {
     if (!ok) return;
     if (++depth > 16) { ok = false; return; }
@@ -116,21 +119,24 @@ struct Reader {
       case T_I16: case T_I32: case T_I64: varint(); break;
       case T_DOUBLE: skip_bytes(8); break;
       case T_BINARY: skip_bytes(varint()); break;
+      // containers: every element takes at least one byte (a bool inside a container is a byte of
+      // its own, unlike a bool field), so a count beyond the bytes left is corrupt -- without this
+      // bound a map<bool, bool> with a 2^60 count consumed nothing per element and never ended
       case T_LIST: case T_SET: {
         const uint8_t h = byte();
         uint64_t n = h >> 4;
         if (n == 15) n = varint();
+        if (n > (uint64_t)(end - p)) { ok = false; break; }
         const int et = h & 0x0F;
-        for (uint64_t i = 0; i < n && ok; ++i) {
-          if (et == T_TRUE || et == T_FALSE) byte(); else skip(et);  // bools in a list take a byte
-        }
+        for (uint64_t i = 0; i < n && ok; ++i) skip_element(et);
         break;
       }
       case T_MAP: {
         const uint64_t n = varint();
+        if (n > (uint64_t)(end - p)) { ok = false; break; }
         if (n) {
           const uint8_t kv = byte();
-          for (uint64_t i = 0; i < n && ok; ++i) { skip(kv >> 4); skip(kv & 0x0F); }
+          for (uint64_t i = 0; i < n && ok; ++i) { skip_element(kv >> 4); skip_element(kv & 0x0F); }
         }
         break;
       }

@@ -185,6 +185,69 @@ int main(int argc, char** argv) {
   CHECK(IsEncodingSupported(Encoding::FLE) && IsEncodingSupported(Encoding::FLE_DICTIONARY) &&
         !IsEncodingSupported(Encoding::DELTA_BINARY_PACKED) && !IsEncodingSupported(Encoding::RLE_DICTIONARY));
 
+  // 7b. regression: a skipped map<bool, bool> field with an absurd element count used to spin for
+  //     2^62 iterations without consuming a byte
+  {
+    const uint8_t evil[] = {0x9B, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0x3F, 0x11, 0x00};
+    PageHeader hh;
+    uint32_t l = sizeof(evil);
+    CHECK(!DeserializeThriftMsg(evil, &l, true, &hh));
+    const uint8_t evil_list[] = {0x99, 0xF1, 0xFF, 0xFF, 0xFF, 0xFF, 0x0F, 0x00};  // list<bool>, 2^32 elements
+    l = sizeof(evil_list);
+    CHECK(!DeserializeThriftMsg(evil_list, &l, true, &hh));
+  }
+
+  // 8. corrupt input never reads or writes out of bounds (this binary runs under ASan + UBSan):
+  //    random bytes and mutated valid streams through the header reader and both decompressors;
+  //    whatever they answer, a "true" must come with consistent sizes
+  {
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    PageHeader good;
+    good.type = PageType::DATA_PAGE;
+    good.uncompressed_page_size = 5000;
+    good.compressed_page_size = 1234;
+    good.__isset.data_page_header = true;
+    good.data_page_header.num_values = 4096;
+    good.data_page_header.encoding = Encoding::FLE_DICTIONARY;
+    good.data_page_header.definition_level_encoding = Encoding::FLE;
+    good.data_page_header.repetition_level_encoding = Encoding::BIT_PACKED;
+    std::vector<uint8_t> good_bytes;
+    SerializePageHeader(good, &good_bytes);
+    std::vector<uint8_t> text(3000), packed, packed_gz;
+    for (size_t i = 0; i < text.size(); ++i) text[i] = (uint8_t)("abcabcabd"[i % 9] + (i / 700));
+    CHECK(Compress(CompressionCodec::SNAPPY, text.data(), (int64_t)text.size(), &packed));
+    CHECK(Compress(CompressionCodec::GZIP, text.data(), (int64_t)text.size(), &packed_gz));
+    int accepted = 0;
+    for (int it = 0; it < 20000; ++it) {
+      // (a) header: random bytes, or the valid header with a few bytes changed / truncated
+      std::vector<uint8_t> b;
+      if (it & 1) {
+        b.resize(1 + rnd() % 40);
+        for (auto& c : b) c = (uint8_t)rnd();
+      } else {
+        b = good_bytes;
+        for (int k = 0; k < 1 + (int)(rnd() % 3); ++k) b[rnd() % b.size()] = (uint8_t)rnd();
+        if (rnd() % 4 == 0) b.resize(1 + rnd() % b.size());
+      }
+      PageHeader h;
+      uint32_t len = (uint32_t)b.size();
+      if (DeserializeThriftMsg(b.data(), &len, true, &h)) {
+        ++accepted;
+        CHECK(len <= b.size());
+      }
+      // (b) Snappy / GZIP: mutated valid streams and random bytes, random claimed sizes
+      std::vector<uint8_t> c = (it % 3 == 0) ? packed : (it % 3 == 1) ? packed_gz : std::vector<uint8_t>(1 + rnd() % 64);
+      if (it % 3 == 2) for (auto& v : c) v = (uint8_t)rnd();
+      else for (int k = 0; k < 1 + (int)(rnd() % 4); ++k) c[rnd() % c.size()] = (uint8_t)rnd();
+      const int64_t claimed = (it % 5 == 0) ? (int64_t)(rnd() % 8000) : (int64_t)text.size();
+      std::vector<uint8_t> outb;
+      const int codec = (it % 3 == 1) ? CompressionCodec::GZIP : CompressionCodec::SNAPPY;
+      if (Decompress(codec, c.data(), (int64_t)c.size(), claimed, &outb)) CHECK((int64_t)outb.size() == claimed);
+    }
+    CHECK(accepted > 0);  // the mutation loop does reach the accepting paths
+  }
+
   printf("host_page_header_test: %d failed\n", g_fail);
   return g_fail ? 1 : 0;
 }
