@@ -276,12 +276,18 @@ inline bool CodecSupported(int codec) {
 inline bool Decompress(int codec, const uint8_t* in, int64_t in_len, int64_t uncompressed_size,
                        std::vector<uint8_t>* out) {
   if (in_len < 0 || uncompressed_size < 0) return false;
+  // a corrupt header must not turn into a multi-gigabyte allocation: pages are megabytes; the
+  // sizes are int32 in the thrift struct, half of that range is refused outright
+  constexpr int64_t kMaxPageBytes = 1ll << 30;
+  if (uncompressed_size > kMaxPageBytes) return false;
   if (codec == CompressionCodec::UNCOMPRESSED) {
     if (in_len != uncompressed_size) return false;
     out->assign(in, in + in_len);
     return true;
   }
   if (codec == CompressionCodec::SNAPPY) {
+    int hdr = 0;
+    if (snappy::UncompressedLength(in, in_len, &hdr) != uncompressed_size) return false;  // before allocating
     out->assign((size_t)uncompressed_size, 0);
     return snappy::Uncompress(in, in_len, out->data(), uncompressed_size);
   }
