@@ -21,6 +21,7 @@
 #include "../util/dict-encoding.h"
 #include "parquet-common.h"
 #include "parquet-page-header.h"
+#include "parquet-column-chunk.h"
 
 namespace impala {
 
@@ -65,26 +66,7 @@ class HdfsParquetScanner {
     // not make the decoders read outside the buffer.
     static bool SplitDataPage(uint8_t* data, int len, int max_def_level, uint8_t** def_levels,
                               int* n_def_bytes, uint8_t** codes, int* codes_len) {
-      uint8_t* p = data;
-      int left = len;
-      *def_levels = nullptr;
-      *n_def_bytes = 0;
-      if (data == nullptr || len < 0) return false;
-      if (max_def_level > 0) {
-        if (left < 4) return false;
-        int32_t nb;
-        memcpy(&nb, p, 4);
-        p += 4; left -= 4;
-        if (nb < 0 || nb > left) return false;
-        *def_levels = p;
-        *n_def_bytes = nb;
-        p += nb; left -= nb;
-      }
-      if (left < 1) return false;  // the code-width byte (DictDecoderBase::SetData)
-      if (*p < 1 || *p > 32) return false;
-      *codes = p;
-      *codes_len = left;
-      return true;
+      return parquet::SplitDataPage(data, len, max_def_level, def_levels, n_def_bytes, codes, codes_len);
     }
 
    protected:
@@ -362,66 +344,16 @@ class HdfsParquetScanner {
       ips::ok(IPS_ERR_INVALID_ARG, msg);
       return -1;
     };
-    if (!parquet::CodecSupported(codec)) return fail("compression codec not supported (UNCOMPRESSED, SNAPPY and GZIP are)");
-    if (chunk == nullptr || chunk_len < 0 || num_values < 0) return fail("bad column chunk");
-    std::vector<std::unique_ptr<std::vector<uint8_t>>> owned;
-    std::vector<uint8_t>* dict_values = nullptr;
-    struct DataPage { std::vector<uint8_t>* bytes; int64_t num_values; int encoding; };
-    std::vector<DataPage> data_pages;
-    int64_t pos = 0, num_values_read = 0;
-    while (num_values_read < num_values) {  // .cc:741-748
-      if (pos >= chunk_len) return fail("column metadata states more values than the pages hold");  // PARQUET_COLUMN_METADATA_INVALID
-      parquet::PageHeader header;
-      uint32_t header_size = (uint32_t)std::min<int64_t>(chunk_len - pos, 1 << 20);
-      if (!parquet::DeserializeThriftMsg(chunk + pos, &header_size, true, &header))
-        return fail("could not read the page header");  // .cc:762-798
-      pos += header_size;
-      const int64_t data_size = header.compressed_page_size;
-      const int64_t uncompressed_size = header.uncompressed_page_size;
-      if (data_size < 0 || uncompressed_size < 0 || pos + data_size > chunk_len) return fail("page runs past the column chunk");
-      if (header.type == parquet::PageType::DICTIONARY_PAGE) {  // .cc:806-853
-        if (dict_values) return fail("Column chunk should not contain two dictionary pages.");
-        if (!header.__isset.dictionary_page_header) return fail("Dictionary page does not have dictionary header set.");
-        const int e = header.dictionary_page_header.encoding;
-        if (e != parquet::Encoding::PLAIN && e != parquet::Encoding::PLAIN_DICTIONARY && e != parquet::Encoding::FLE_DICTIONARY)
-          return fail("Only PLAIN and PLAIN_DICTIONARY encodings are supported for dictionary pages.");
-        owned.emplace_back(new std::vector<uint8_t>());
-        if (!parquet::Decompress(codec, chunk + pos, data_size, uncompressed_size, owned.back().get()))
-          return fail("dictionary page does not decompress to its stated size");
-        dict_values = owned.back().get();
-        if ((int64_t)dict_values->size() != (int64_t)header.dictionary_page_header.num_values * ips_plain_stride(IpsTypeOf<T>::value))
-          return fail("Invalid dictionary. Entry count differs from the dictionary page header");  // .cc:845-850
-        pos += data_size;
-        continue;
-      }
-      if (header.type != parquet::PageType::DATA_PAGE || !header.__isset.data_page_header) {
-        pos += data_size;  // "We can safely skip non-data pages", .cc:855-859
-        continue;
-      }
-      const parquet::DataPageHeader& dh = header.data_page_header;
-      if (dh.num_values < 0) return fail("negative value count in a data page header");
-      if (!parquet::IsEncodingSupported(dh.encoding)) return fail("unsupported data page encoding");  // .cc:1637-1649
-      // the vectorised predicates read the levels with fle_def_levels_ whatever the header says
-      // (.cc:342 vs :885-912): refuse instead of dereferencing NULL
-      if (max_def_level > 0 && dh.definition_level_encoding != parquet::Encoding::FLE)
-        return fail("definition levels are not FLE encoded: this page needs the row-at-a-time path");
-      owned.emplace_back(new std::vector<uint8_t>());
-      if (!parquet::Decompress(codec, chunk + pos, data_size, uncompressed_size, owned.back().get()))
-        return fail("data page does not decompress to its stated size");
-      pos += data_size;
-      num_values_read += dh.num_values;
-      if (dh.num_values == 0) continue;
-      data_pages.push_back(DataPage{owned.back().get(), dh.num_values, dh.encoding});
-    }
-    if (num_values_read != num_values) return fail("pages hold more values than the column metadata states");
-    if (data_pages.empty()) return fail("column chunk without data pages");
-    const bool dict_coded = data_pages[0].encoding == parquet::Encoding::PLAIN_DICTIONARY ||
-                            data_pages[0].encoding == parquet::Encoding::FLE_DICTIONARY;
-    for (const DataPage& pg : data_pages) {
-      const bool d = pg.encoding == parquet::Encoding::PLAIN_DICTIONARY || pg.encoding == parquet::Encoding::FLE_DICTIONARY;
-      if (d != dict_coded || (!d && pg.encoding != parquet::Encoding::PLAIN))
-        return fail("mixed page encodings inside one column chunk are not supported");
-    }
+    // the host-only part (headers, codecs, page bookkeeping) lives in parquet-column-chunk.h
+    parquet::ColumnChunkPages pages;
+    if (const char* msg = parquet::WalkColumnChunk(chunk, chunk_len, num_values, codec, max_def_level,
+                                                   ips_plain_stride(IpsTypeOf<T>::value), &pages))
+      return fail(msg);
+    auto& owned = pages.owned;
+    std::vector<uint8_t>* dict_values = pages.dict_values;
+    auto& data_pages = pages.data_pages;
+    using DataPage = parquet::ChunkDataPage;
+    const bool dict_coded = pages.dict_coded;
     int idx;
     if (dict_coded) {
       if (!dict_values) return fail("File corrupt. Missing dictionary page.");  // .cc:458-460
@@ -434,18 +366,8 @@ class HdfsParquetScanner {
       // PLAIN pages: the values follow the level bytes (data_ += num_definition_bytes, .cc:916-917);
       // the PLAIN branch of the predicates ignores the levels (quirk Q3)
       auto values_of = [&](const DataPage& pg, uint8_t** v) -> bool {
-        uint8_t* p = pg.bytes->data();
-        int64_t left = (int64_t)pg.bytes->size();
-        if (max_def_level > 0) {
-          if (left < 4) return false;
-          int32_t nb;
-          memcpy(&nb, p, 4);
-          if (nb < 0 || nb > left - 4) return false;
-          p += 4 + nb; left -= 4 + nb;
-        }
-        if (left < pg.num_values * ips_plain_stride(IpsTypeOf<T>::value)) return false;
-        *v = p;
-        return true;
+        return parquet::PlainPageValues(pg.bytes->data(), (int64_t)pg.bytes->size(), max_def_level, pg.num_values,
+                                        ips_plain_stride(IpsTypeOf<T>::value), v);
       };
       uint8_t* v = nullptr;
       if (!values_of(data_pages[0], &v)) return fail("truncated PLAIN data page");

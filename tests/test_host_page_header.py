@@ -62,3 +62,16 @@ def test_snappy_against_libsnappy(tmp_path):
         assert codec.decompress(ours, decompressed_size=len(raw), asbytes=True) == raw, name
         if name in ("text", "runs"):
             assert len(ours) < len(raw) // 8
+
+
+def test_column_chunk_walk_and_fuzz(tmp_path):
+    """tests/host_column_chunk_test.cpp: the host-only column-chunk walk + data-page framing on valid
+    chunks (3 codecs x PLAIN / dictionary x REQUIRED / OPTIONAL) and 18 000 corrupted ones, ASan + UBSan."""
+    exe = str(tmp_path / "host_column_chunk_test")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-o", exe,
+                           os.path.join(ROOT, "tests", "host_column_chunk_test.cpp"), "-lz"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 failed" in r.stdout
