@@ -50,10 +50,12 @@ int device_cus() {
 }
 
 // Blocks launched per resident block slot.  A grid of exactly the resident size finishes on its
-// slowest CU; 4x smaller work shares let the dispatcher even that out (measured: +3..6 % on the
-// w=32 scan and predicate kernels; 8x and more start to cost the narrow widths their prologue).  IPS_GRID_MULT overrides it (dev knob).
+// slowest CU; smaller work shares let the dispatcher even that out (round 1: 4x, +3..6 % on the
+// w=32 scan and predicate kernels; end of round 2, with the narrow scans at 8 waves per SIMD: 8x is
+// neutral at w=32 and 3-5 % faster at w <= 16, 12x and more cost the early-pruning predicate its
+// prefetch).  IPS_GRID_MULT overrides it (dev knob).
 int grid_mult() {
-  static int m = [] { const char* e = getenv("IPS_GRID_MULT"); int v = e ? atoi(e) : 4; return v > 0 ? v : 4; }();
+  static int m = [] { const char* e = getenv("IPS_GRID_MULT"); int v = e ? atoi(e) : 8; return v > 0 ? v : 8; }();
   return m;
 }
 
