@@ -44,9 +44,13 @@ constexpr int kDecodeDictLdsBytes = 32768;
 // Long IN lists on narrow columns (every dictionary code width): membership becomes a 2^W-bit set
 // in LDS, built once per workgroup, and each decoded value costs one LDS read -- independent of
 // the list length -- instead of W bit-select steps per constant.
-// Below in_table_min_consts(W) constants the K * W plane steps on registers are cheaper than
-// decoding every row and looking it up (about 48..112 ops of transposition + 6 per row).
-constexpr int in_table_min_consts(int w) { return w <= 8 ? 32 : w <= 12 ? 26 : 20; }
+// Below these list lengths the K * W plane steps on registers are cheaper than decoding every row
+// and looking it up (48..112 ops of transposition + 6 per row).  Crossovers measured at 2^28 rows
+// at the end of round 2 (tools/ab/in_table_sweep.py), separately for the fused scan -- whose list
+// variants run at 8 / 5 waves per SIMD while the table variant of w > 8 needs the large LDS layout
+// -- and for the stand-alone predicate.
+constexpr int in_table_min_consts(int w) { return w <= 8 ? 20 : w <= 12 ? 34 : 22; }        // fused scan
+constexpr int in_table_min_consts_pred(int w) { return w <= 8 ? 20 : w <= 12 ? 22 : 14; }  // predicate only
 template <int W>
 struct InTable {
   static constexpr bool kUse = W <= 16;
@@ -104,14 +108,18 @@ struct ScanLds {
   // layout, WITHOUT a dense path: beyond 512 selected rows of a sub-tile they work the index list
   // off in windows of 512 (kWindowed) -- slow there, but their registers then fit 5 waves per SIMD.
   static constexpr bool kWindowed = IPS_SCAN_SMALL_LDS && IPS_INDEX_PATH && MODE == kScanInList && W > IPS_SCAN_SMALL_LDS_MAX_W && W <= 16;
-  static constexpr bool kSmall = IPS_SCAN_SMALL_LDS && IPS_INDEX_PATH && MODE != kScanInTable &&
-                                 (W <= IPS_SCAN_SMALL_LDS_MAX_W || kWindowed);
+  // (membership-table scans of w <= 8 as well: the decoded values are only needed for the lookup,
+  // what is parked are the lane-packed bytes)
+  static constexpr bool kSmall = IPS_SCAN_SMALL_LDS && IPS_INDEX_PATH &&
+                                 (MODE != kScanInTable ? (W <= IPS_SCAN_SMALL_LDS_MAX_W || kWindowed)
+                                                       : W <= IPS_SCAN_SMALL_LDS_MAX_W);
   static constexpr int kBody = !kSmall ? kRowTileBytes : W <= 8 ? 64 * packed_lane_stride(8) : 64 * packed_lane_stride(16);
   static constexpr int kWaveBytes = kBody + kIndexListBytes;  // 4096 / 6144 / 10240
   static_assert(plane_tile_bytes(kSmall ? (W <= 8 ? 8 : 16) : 32) <= kBody, "the plane image fits the body");
   // waves per SIMD the register allocation is asked to allow (without the dense path's 32 value
   // registers the narrow scans need 46-61 (w <= 8) and 79-96 (w <= 16) VGPRs)
-  static constexpr int kMinWaves = !kSmall ? IPS_MIN_WAVES_PER_EU : W <= IPS_SCAN_SMALL_LDS_MAX_W ? 8 : 5;
+  static constexpr int kMinWaves = !kSmall ? IPS_MIN_WAVES_PER_EU : MODE == kScanInTable ? 6  // (32 decoded values live during the lookup)
+                                   : W <= IPS_SCAN_SMALL_LDS_MAX_W ? 8 : 5;
 };
 
 // first_tile / stride: the sub-tiles this wave takes (tile = first_tile, first_tile + stride, ...)
@@ -284,7 +292,7 @@ __device__ __forceinline__ void fle_scan_body(
         continue;
       }
       constexpr int R = LaneWidth<W>::R;
-      constexpr bool kPacked = IPS_INDEX_PATH && !kInTable && R < 32;  // values stay lane-packed
+      constexpr bool kPacked = IPS_INDEX_PATH && R < 32;  // values stay lane-packed (table mode too: its decoded dwords are only for the lookup)
 #ifndef IPS_QUADS
 #define IPS_QUADS 1
 #endif
@@ -292,7 +300,7 @@ __device__ __forceinline__ void fle_scan_body(
 #ifndef IPS_QUADS16
 #define IPS_QUADS16 1  // w=16 / 12 / 10 LT @10 %: 134 -> 117 / 127 -> 111 / 114 -> 100 us
 #endif
-      constexpr bool kQuads16 = IPS_QUADS16 && kPacked && R == 16;
+      constexpr bool kQuads16 = IPS_QUADS16 && kPacked && !kInTable && R == 16;
       const bool index_path = IPS_INDEX_PATH ? (kWindowed || count <= (uint32_t)kIndexListMax)
                                              : __builtin_amdgcn_ballot_w64(mine > kSparseLaneMax) == 0ull;
       if (IPS_INDEX_PATH && index_path) {

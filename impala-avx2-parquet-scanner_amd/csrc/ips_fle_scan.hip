@@ -13,6 +13,15 @@
 
 namespace ips {
 
+// IN lists of at least this many constants take the membership-table path (dev override:
+// IPS_IN_TABLE_MIN=<K> for every width)
+static int in_table_forced() {
+  static const int forced = [] { const char* e = getenv("IPS_IN_TABLE_MIN"); return e ? atoi(e) : 0; }();
+  return forced;
+}
+static int in_table_min(int w) { return in_table_forced() > 0 ? in_table_forced() : in_table_min_consts(w); }
+static int in_table_min_pred(int w) { return in_table_forced() > 0 ? in_table_forced() : in_table_min_consts_pred(w); }
+
 template <int W, int MODE, int G>
 static ips_status launch_one(const uint64_t* enc, int64_t n_rows, const PredArgs& args,
                              uint32_t* bitmap32, const uint32_t* given32, void* batch_values,
@@ -41,7 +50,7 @@ static ips_status launch_w(int mode, int gather, const uint64_t* enc, int64_t n_
     if (mode == kScanPredicate) return launch_one<W, kScanPredicate, 0>(IPS_ARGS);
     if (mode == kScanInList) {
       if constexpr (W <= 16) {
-        if (args.n_consts >= in_table_min_consts(W)) return launch_one<W, kScanInTable, 0>(IPS_ARGS);
+        if (args.n_consts >= in_table_min(W)) return launch_one<W, kScanInTable, 0>(IPS_ARGS);
       }
       return launch_one<W, kScanInList, 0>(IPS_ARGS);
     }
@@ -52,7 +61,7 @@ static ips_status launch_w(int mode, int gather, const uint64_t* enc, int64_t n_
       if (gather == 4) return launch_one<W, kScanPredicate, 4>(IPS_ARGS);
       if (gather == 8) return launch_one<W, kScanPredicate, 8>(IPS_ARGS);
     }
-    if (mode == kScanInList && args.n_consts >= in_table_min_consts(W)) {
+    if (mode == kScanInList && args.n_consts >= in_table_min(W)) {
       if (gather == 4) return launch_one<W, kScanInTable, 4>(IPS_ARGS);
       if (gather == 8) return launch_one<W, kScanInTable, 8>(IPS_ARGS);
     }
@@ -146,7 +155,7 @@ static ips_status launch_pred_w(const uint64_t* enc, int64_t n_rows, const PredA
   if (args.join != 0) return launch_pred_wk<W, kPredPair>(enc, n_rows, args, bitmap32, s);
   if (args.op == 5) {
     if constexpr (W <= 16) {
-      if (args.n_consts >= in_table_min_consts(W)) return launch_pred_wk<W, kPredInTable>(enc, n_rows, args, bitmap32, s);
+      if (args.n_consts >= in_table_min_pred(W)) return launch_pred_wk<W, kPredInTable>(enc, n_rows, args, bitmap32, s);
     }
     return launch_pred_wk<W, kPredInList>(enc, n_rows, args, bitmap32, s);
   }
