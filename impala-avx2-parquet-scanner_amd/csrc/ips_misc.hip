@@ -379,7 +379,11 @@ constexpr int kTupleImageMax = 128;  // tuples up to this size are staged throug
 // dword i * ts / 4 + d, which for 16 / 32 / 64-byte tuples put 4 / 8 / 16 lanes on every bank
 // (68 % of the LDS cycles of the 16-byte case were conflicts); with the pad, lanes whose logical
 // dwords are 64 apart land on neighbouring banks, and the linear read-out stays conflict-free.
-__device__ __forceinline__ uint32_t img(uint32_t byte) { return byte + ((byte >> 8) << 2); }
+// Measured (2^28 rows @10 %): the pad costs the read-out its 16-byte LDS reads and an add per access;
+// 64-byte tuples gain 25 % from it (637 -> 474 us), 24- and 32-byte tuples LOSE 11-19 %, so it is
+// applied from 64 bytes up (kTuplePadMin).
+constexpr int kTuplePadMin = 64;
+__device__ __forceinline__ uint32_t img(uint32_t byte, bool pad) { return pad ? byte + ((byte >> 8) << 2) : byte; }
 
 // FAST tuples of at most 16 bytes never touch LDS: the lane builds its tuple in registers and the
 // 64 tuples of a round leave as one coalesced store (4 / 8 / 12 / 16 bytes per lane).  Its own
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(kThreads) void assemble_small_kernel(
   }
 }
 
-template <bool IMAGE, bool FAST>
+template <bool IMAGE, bool FAST, bool PAD>
 __global__ __launch_bounds__(kThreads) void assemble_tuples_kernel(
     TupleCols tc, const uint32_t* __restrict__ counts, int64_t n_batches,
     const uint64_t* __restrict__ batch_off, uint8_t* __restrict__ tuples) {
@@ -446,7 +450,8 @@ __global__ __launch_bounds__(kThreads) void assemble_tuples_kernel(
   const int lane = lane_id();
   const int wave = wave_id();
   const int ts = tc.tuple_size;
-  uint8_t* image = image_all + (IMAGE ? wave * (int)img((uint32_t)(kWave * ts)) : 0);
+  constexpr bool pad = PAD;  // tuples of kTuplePadMin bytes and more (chosen by the launcher)
+  uint8_t* image = image_all + (IMAGE ? wave * (int)img((uint32_t)(kWave * ts), pad) : 0);
   const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
   for (int64_t batch = (int64_t)blockIdx.x * kWavesPerBlock + wave; batch < n_batches;
        batch += stride) {
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(kThreads) void assemble_tuples_kernel(
       // the lane's tuple: image + img(lane * ts + byte) (IMAGE) or its place in the output
       const uint32_t t0 = (uint32_t)(lane * ts);
       uint8_t* t = IMAGE ? image : tuples + (first + i) * (uint64_t)ts;
-      auto at = [&](int byte) -> uint8_t* { return IMAGE ? image + img(t0 + (uint32_t)byte) : t + byte; };
+      auto at = [&](int byte) -> uint8_t* { return IMAGE ? image + img(t0 + (uint32_t)byte, pad) : t + byte; };
       if (IMAGE) {
 #pragma unroll
         for (int d = 0; d < kTupleImageMax / 4; ++d)
@@ -514,14 +519,19 @@ __global__ __launch_bounds__(kThreads) void assemble_tuples_kernel(
         uint8_t* dst = tuples + (first + i0) * (uint64_t)ts;
         const uint32_t bytes = in_round * (uint32_t)ts;
         if ((ts & 15) == 0) {  // 16-byte pieces: the destination is 16-byte aligned as well
-          for (uint32_t o = lane * 16; o < bytes; o += kWave * 16) {
-            const uint32_t* src4 = reinterpret_cast<const uint32_t*>(image + img(o));  // a piece never straddles a pad
-            const u32x4 v = {src4[0], src4[1], src4[2], src4[3]};
-            aux_store(reinterpret_cast<u32x4*>(dst + o), v);
+          if (pad) {
+            for (uint32_t o = lane * 16; o < bytes; o += kWave * 16) {
+              const uint32_t* src4 = reinterpret_cast<const uint32_t*>(image + img(o, true));  // a piece never straddles a pad
+              const u32x4 v = {src4[0], src4[1], src4[2], src4[3]};
+              aux_store(reinterpret_cast<u32x4*>(dst + o), v);
+            }
+          } else {
+            for (uint32_t o = lane * 16; o < bytes; o += kWave * 16)
+              aux_store(reinterpret_cast<u32x4*>(dst + o), *reinterpret_cast<const u32x4*>(image + o));
           }
         } else {
           for (uint32_t o = lane * 4; o < bytes; o += kWave * 4)
-            *reinterpret_cast<uint32_t*>(dst + o) = *reinterpret_cast<const uint32_t*>(image + img(o));
+            *reinterpret_cast<uint32_t*>(dst + o) = *reinterpret_cast<const uint32_t*>(image + img(o, pad));
         }
         wave_lds_fence();
       }
@@ -598,8 +608,9 @@ ips_status launch_assemble_tuples(const ips_tuple_column* cols, int n_cols, cons
   for (int i = 0; i < n_cols; ++i)
     fast = fast && !cols[i].d_nonnull_flags && cols[i].value_width == 4 && (cols[i].tuple_offset & 3) == 0;
   const size_t wave_image = (size_t)kWave * tuple_size;
-  const size_t lds = image ? (size_t)kWavesPerBlock * (wave_image + ((wave_image >> 8) << 2)) : 0;
+  const size_t lds = image ? (size_t)kWavesPerBlock * (wave_image + (tuple_size >= kTuplePadMin ? ((wave_image >> 8) << 2) : 0)) : 0;
   uint8_t* out = reinterpret_cast<uint8_t*>(tuples);
+  const bool pad = tuple_size >= kTuplePadMin;
   if (fast && tuple_size <= 16) {
     SmallTupleCols sc;
     memset(&sc, 0, sizeof(sc));
@@ -613,14 +624,20 @@ ips_status launch_assemble_tuples(const ips_tuple_column* cols, int n_cols, cons
 #define IPS_SMALL(TS) hipLaunchKernelGGL((assemble_small_kernel<TS>), dim3(grid), dim3(kThreads), 0, s, sc, counts, n_batches, batch_off, out)
     if (tuple_size == 16) IPS_SMALL(16); else if (tuple_size == 12) IPS_SMALL(12); else if (tuple_size == 8) IPS_SMALL(8); else IPS_SMALL(4);
 #undef IPS_SMALL
-  } else if (fast)
-    hipLaunchKernelGGL((assemble_tuples_kernel<true, true>), dim3(grid), dim3(kThreads), lds, s, tc,
+  } else if (fast && pad)
+    hipLaunchKernelGGL((assemble_tuples_kernel<true, true, true>), dim3(grid), dim3(kThreads), lds, s, tc,
                        counts, n_batches, batch_off, out);
+  else if (fast)
+    hipLaunchKernelGGL((assemble_tuples_kernel<true, true, false>), dim3(grid), dim3(kThreads), lds, s, tc,
+                       counts, n_batches, batch_off, out);
+  else if (image && pad)
+    hipLaunchKernelGGL((assemble_tuples_kernel<true, false, true>), dim3(grid), dim3(kThreads), lds, s,
+                       tc, counts, n_batches, batch_off, out);
   else if (image)
-    hipLaunchKernelGGL((assemble_tuples_kernel<true, false>), dim3(grid), dim3(kThreads), lds, s,
+    hipLaunchKernelGGL((assemble_tuples_kernel<true, false, false>), dim3(grid), dim3(kThreads), lds, s,
                        tc, counts, n_batches, batch_off, out);
   else
-    hipLaunchKernelGGL((assemble_tuples_kernel<false, false>), dim3(grid), dim3(kThreads), 0, s, tc,
+    hipLaunchKernelGGL((assemble_tuples_kernel<false, false, false>), dim3(grid), dim3(kThreads), 0, s, tc,
                        counts, n_batches, batch_off, out);
   IPS_HIP_TRY(hipGetLastError());
   return IPS_OK;
