@@ -73,7 +73,7 @@ struct ips_comm {
   std::vector<hipEvent_t> events;  // grow-only pool, reused round-robin (created outside captures)
   size_t next_event = 0;
   hipEvent_t event() {
-    if (events.size() < 64) {
+    if (events.size() < 192) {  // two steps of up to 64 chunk events + joins can be pending
       hipEvent_t e = nullptr;
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
       events.push_back(e);
@@ -164,16 +164,23 @@ ips_status ips_fle_scan_allgather(ips_comm* comm, const void* d_enc, int64_t n_r
   const int64_t rows_c = n_rows / n_chunks;
   const int64_t words_c = rows_c / 64;
   const uint8_t* enc = reinterpret_cast<const uint8_t*>(d_enc);
+  // all chunk scans (and the event after each) go to the scan stream first, the gathers second: an
+  // ncclAllGather call takes the host 10-20 us, and issued between the scans it left the GPU idle
+  // between chunk kernels
+  IPS_REQUIRE(n_chunks <= 64, "ips_fle_scan_allgather: at most 64 chunks per step");
+  hipEvent_t done[64];
   for (int i = 0; i < n_chunks; ++i) {
     ips_status st = ips_fle_scan(enc + (size_t)i * (size_t)words_c * (size_t)bit_width * 8, rows_c, bit_width,
                                  op, consts, n_consts, d_local_bitmap + (size_t)i * words_c,
                                  d_batch_values + (size_t)i * rows_c,
                                  d_batch_counts + (size_t)i * (rows_c / IPS_BATCH_ROWS), stream);
     if (st != IPS_OK) return st;
-    hipEvent_t done = comm->event();
-    IPS_REQUIRE(done != nullptr, "ips_fle_scan_allgather: cannot create an event");
-    IPS_HIP_TRY(hipEventRecord(done, s));
-    IPS_HIP_TRY(hipStreamWaitEvent(comm->stream, done, 0));
+    done[i] = comm->event();
+    IPS_REQUIRE(done[i] != nullptr, "ips_fle_scan_allgather: cannot create an event");
+    IPS_HIP_TRY(hipEventRecord(done[i], s));
+  }
+  for (int i = 0; i < n_chunks; ++i) {
+    IPS_HIP_TRY(hipStreamWaitEvent(comm->stream, done[i], 0));
     // piece (i, rank) of the block-cyclic layout: chunk i of all ranks is contiguous in the column
     int rc = r->AllGather(d_local_bitmap + (size_t)i * words_c,
                           d_all_bitmap + (size_t)i * (size_t)comm->nranks * words_c, (size_t)words_c,
