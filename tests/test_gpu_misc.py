@@ -108,6 +108,8 @@ def test_narrow_dictionary_scan_every_selectivity(capi, O, type_name, distinct):
         bw, blocks = page_blocks(data)
         dd = capi.Dict(dict_page, t)
         enc = dev_words(blocks)
+        out, bad = dd.decode(enc, n, bw)   # the packed decode path: 4- and 8-byte entries, ragged n
+        assert int(bad.item()) == 0 and np.array_equal(out.cpu().numpy().astype(O.NP_TYPES[t]), vals)
         for q in (0.0, 0.02, 0.2, 0.3, 0.6, 1.0):
             lit = d[min(len(d) - 1, int(q * len(d)))]
             for op in ((O.OP_LT, O.OP_GE) if q < 1.0 else (O.OP_LE,)):
