@@ -101,7 +101,9 @@ int grid_for_tiles(const void* kernel, int64_t tiles) {
   ips_status launch_fle_pred_part_##P(int, const uint64_t*, int64_t, const PredArgs&, uint32_t*, \
                                       hipStream_t);                                             \
   ips_status launch_fle_scan_pages_part_##P(int, const PageBatch&, int, int64_t,                \
-                                            const PredArgs&, hipStream_t);
+                                            const PredArgs&, hipStream_t);                      \
+  ips_status launch_fle_leaf_part_##P(int, const uint64_t*, int64_t, const PredArgs&, uint64_t*, \
+                                      bool*, hipStream_t);
 IPS_DECL_PARTS(a) IPS_DECL_PARTS(b) IPS_DECL_PARTS(c) IPS_DECL_PARTS(d)
 
 ips_status launch_bitmap_binop(int op, uint64_t* a, const uint64_t* b, int64_t n_words, hipStream_t s);
@@ -152,6 +154,36 @@ ips_status launch_fle_pred(int w, const uint64_t* enc, int64_t n_rows, const Pre
   if (w <= 16) return launch_fle_pred_part_b(w, enc, n_rows, args, bitmap32, s);
   if (w <= 24) return launch_fle_pred_part_c(w, enc, n_rows, args, bitmap32, s);
   return launch_fle_pred_part_d(w, enc, n_rows, args, bitmap32, s);
+}
+
+bool fused_leaf_enabled() {  // dev switch for A/B runs
+  static const bool on = getenv("IPS_NO_FUSED_LEAF") == nullptr;
+  return on;
+}
+
+// The nullable leaf in one launch (fle_leaf_kernel); the tile counts of the root must be complete
+// on the stream.  *taken = false: the shape keeps the three-launch route, nothing was launched.
+ips_status launch_fle_leaf(int w, int root_kind, const uint64_t* root, int64_t n_rows,
+                           const uint32_t* tile_counts, const uint64_t* enc, int64_t n_sub,
+                           const PredArgs& pred, uint64_t* out, int combine, bool* taken,
+                           hipStream_t s) {
+  *taken = false;
+  if (!fused_leaf_enabled() || n_sub <= 0 || n_rows <= 0) return IPS_OK;
+  if (n_rows >= (1ll << 40)) {
+    set_error("nullable leaf: %lld rows, the rank arithmetic holds 2^40", (long long)n_rows);
+    return IPS_ERR_INVALID_ARG;
+  }
+  PredArgs args = pred;
+  args.combine = combine;
+  args.aux_blocks = 0;
+  args.aux_kind = root_kind;
+  args.aux_root = root;
+  args.aux_rows = n_rows;
+  args.aux_counts = const_cast<uint32_t*>(tile_counts);
+  if (w <= 8) return launch_fle_leaf_part_a(w, enc, n_sub, args, out, taken, s);
+  if (w <= 16) return launch_fle_leaf_part_b(w, enc, n_sub, args, out, taken, s);
+  if (w <= 24) return launch_fle_leaf_part_c(w, enc, n_sub, args, out, taken, s);
+  return launch_fle_leaf_part_d(w, enc, n_sub, args, out, taken, s);
 }
 
 ips_status launch_fle_encode(int w, int in_width, const void* values, int64_t n_rows,
@@ -363,17 +395,26 @@ static ips_status nullable_leaf(const void* d_def_levels, int def_bit_width, int
                                         &root_kind, &root, s, /*count_tiles=*/false);
   if (st != IPS_OK) return st;
   int64_t n_sub = n_data_rows < n_rows ? n_data_rows : n_rows;  // a page holds no more data rows than rows
+  const uint64_t* enc = reinterpret_cast<const uint64_t*>(d_data_enc);
   if (kind == kAllTrue || n_sub <= 0) {
     st = launch_rank_tile_counts(root_kind, root, n_rows, ws.tile_counts, s);
     if (st == IPS_OK && kind == kAllTrue) {
       n_sub = n_rows;
       st = launch_bitmap_fill(ws.sub, n_rows, 1, s);
     }
+  } else if (fused_leaf_enabled()) {
+    // counts, then predicate + IntersectBitset in one kernel (fle_leaf_kernel); the shapes it
+    // does not take (long IN lists) run predicate and expand as separate launches
+    st = launch_rank_tile_counts(root_kind, root, n_rows, ws.tile_counts, s);
+    if (st != IPS_OK) return st;
+    bool taken = false;
+    st = launch_fle_leaf(bit_width, root_kind, root, n_rows, ws.tile_counts, enc, n_sub, args, d_bitmap, 0, &taken, s);
+    if (st != IPS_OK || taken) return st;
+    st = launch_fle_pred(bit_width, enc, n_sub, args, reinterpret_cast<uint32_t*>(ws.sub), s);
   } else {
     PredArgs with_counts = args;  // the tile counts ride on the data predicate's launch
     attach_rank_counts(&with_counts, root_kind, root, n_rows, ws.tile_counts);
-    st = launch_fle_pred(bit_width, reinterpret_cast<const uint64_t*>(d_data_enc), n_sub, with_counts,
-                         reinterpret_cast<uint32_t*>(ws.sub), s);
+    st = launch_fle_pred(bit_width, enc, n_sub, with_counts, reinterpret_cast<uint32_t*>(ws.sub), s);
   }
   if (st != IPS_OK) return st;
   return launch_expand(root_kind, root, ws.sub, n_rows, n_sub, ws.tile_counts, d_bitmap, 0, s);

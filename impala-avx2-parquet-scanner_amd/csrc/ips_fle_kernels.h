@@ -661,6 +661,162 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_w_ker
 }
 
 // ---------------------------------------------------------------------------------------------
+// The nullable leaf in one pass (ColumnReader's nullable branch, hdfs-parquet-scanner.cc:326-345:
+// predicate over the data rows, then IntersectBitset into the NOT-NULL positions).  A workgroup
+// owns a quarter rank tile of OUTPUT words (1024 words, a wave 256): it forms the rank of its
+// words from the tile counts (as expand_kernel does), evaluates the data predicate on exactly the
+// data blocks that hold rows [rank, rank + NOT-NULL rows of the wave) -- block granular, at most
+// nine sub-tiles -- into a bitmap segment in LDS, and deposits that segment into the NOT-NULL
+// positions.  The data-row bitmap never exists in HBM (the three-launch route writes and re-reads
+// it: 60 MB of 520 on a 2^28-row column) and the levels are read twice instead of three times.
+// args.aux_root / aux_kind / aux_rows / aux_counts: the NOT-NULL root, its kind, the row count
+// and the tile counts (complete before this launch); args.combine: 0 store, 1 and, 2 or into out.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLeafSubTiles = (63 + kExpWordsPerWave * 64 + 2047) / 2048;  // 9
+constexpr int kLeafSegDwords = kLeafSubTiles * 64;
+static_assert(kThreads == kRankThreads, "a leaf workgroup is an expand workgroup");
+
+template <int W, int KIND>
+__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_leaf_kernel(
+    const uint64_t* __restrict__ enc, int64_t n_sub, PredArgs args, u64* __restrict__ out) {
+  static_assert(KIND != kPredInTable, "long IN lists take the three-launch route");
+  __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * plane_tile_bytes(W) / 4];
+  __shared__ uint32_t seg_all[kWavesPerBlock][kLeafSegDwords];
+  __shared__ uint8_t lut[256];
+  __shared__ u64 part[kRankWaves];
+  __shared__ uint32_t wave_tot[kRankWaves];
+  constexpr int L = (16 * W + kWave - 1) / kWave;
+  const int lane = lane_id();
+  const int wave = wave_id();
+  uint32_t* lds32 = lds_all + wave * (plane_tile_bytes(W) / 4);
+  uint32_t* seg = seg_all[wave];
+  lut[threadIdx.x] = (uint8_t)deposit_lut_entry(threadIdx.x);
+
+  const u64* __restrict__ root = reinterpret_cast<const u64*>(args.aux_root);
+  const uint32_t* __restrict__ tile_counts = args.aux_counts;
+  const int64_t n_rows = args.aux_rows;
+  const int64_t n_words = (n_rows + 63) / 64;
+  const int64_t tiles = (n_words + kRankWordsPerTile - 1) / kRankWordsPerTile;
+  const int64_t first = (int64_t)blockIdx.x * kExpWordsPerBlock + wave * kExpWordsPerWave;
+  const bool whole = (first + kExpWordsPerWave) * 64 <= n_rows;  // wave-uniform
+  u64 m[kExpRounds][2];
+  if (args.aux_kind == kRootLevels1) {
+    if (whole) load_root_whole<kRootLevels1, kExpRounds>(root, first, lane, m);
+    else load_root<kRootLevels1, kExpRounds>(root, first, n_words, n_rows, lane, m);
+  } else {
+    if (whole) load_root_whole<kRootBitmap, kExpRounds>(root, first, lane, m);
+    else load_root<kRootBitmap, kExpRounds>(root, first, n_words, n_rows, lane, m);
+  }
+  // rank of the workgroup's first word (see expand_kernel)
+  const int64_t tile = (int64_t)blockIdx.x / kExpBlocksPerTile;
+  const int part_waves = (int)(blockIdx.x % kExpBlocksPerTile) * (kRankWaves / kExpBlocksPerTile);
+  uint32_t before = 0;
+  for (int64_t i = threadIdx.x; i < tile; i += kRankThreads) before += tile_counts[i];
+  if ((int)threadIdx.x < part_waves) before += tile_counts[tiles + tile * kRankWaves + threadIdx.x];
+  {
+    const uint32_t lo = wave_sum(before & 0xFFFFu), hi = wave_sum(before >> 16);
+    if (lane == 0) part[wave] = (u64)lo + ((u64)hi << 16);
+  }
+  uint32_t excl[kExpRounds];
+  uint32_t run = 0;
+#pragma unroll
+  for (int r = 0; r < kExpRounds; ++r) {
+    const uint32_t c = (uint32_t)(__builtin_popcountll(m[r][0]) + __builtin_popcountll(m[r][1]));
+    const uint32_t incl = wave_inclusive_scan(c);
+    excl[r] = run + incl - c;
+    run += __builtin_amdgcn_readlane(incl, 63);
+  }
+  if (lane == 0) wave_tot[wave] = run;
+  __syncthreads();
+  u64 base = part[0] + part[1] + part[2] + part[3];
+  for (int w = 0; w < wave; ++w) base += wave_tot[w];
+
+  // the data predicate over blocks [b0, b0 + n_blk): bitmap dword (k * 64 + lane) of the segment
+  const int64_t b0 = (int64_t)(base >> 6);
+  const uint32_t lead = (uint32_t)(base & 63);
+  const int n_blk = run ? (int)((lead + run + 63u) >> 6) : 0;
+  const int n_st = (n_blk + kBlocksPerTile - 1) / kBlocksPerTile;
+  const int64_t total_words = ((n_sub + 63) / 64) * W;
+  auto load = [&](int k, u32x4 (&r)[L]) {
+    const int64_t w0 = (b0 + (int64_t)k * kBlocksPerTile) * W;
+    int64_t left = total_words - w0;
+    const int64_t need = (int64_t)(n_blk - k * kBlocksPerTile) * W;  // never read past the wave's blocks
+    left = left < need ? left : need;
+    left = left < 0 ? 0 : (left > kBlocksPerTile * W ? kBlocksPerTile * W : left);
+    const uint64_t* bp = left > 0 ? enc + w0 : enc;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(bp), 0, (int)(left * 8), kBufferRsrcDword3);
+#pragma unroll
+    for (int i = 0; i < L; ++i) r[i] = buffer_load16<true>(rsrc, (uint32_t)(i * kWave + lane) * 16u);
+  };
+  u32x4 r[L];
+  if (n_st > 0) load(0, r);
+  for (int k = 0; k < n_st; ++k) {
+    tile_to_lds<L>(lds32, W, lane, r);
+    if (k + 1 < n_st) load(k + 1, r);  // register prefetch
+    wave_lds_fence();
+    uint32_t sel;
+    if (KIND == kPredSingle) {
+      uint32_t p[W];
+      planes_from_lds<W>(lds32, lane, p);
+      sel = pred_from_regs<W>(p, args);
+    } else if (KIND == kPredPair) {
+      uint32_t r1, r2;
+      pred_pair_from_lds(lds32, W, lane, args.op, args.consts[0], args.op2, args.const2, &r1, &r2);
+      sel = args.join == 1 ? (r1 & r2) : (r1 | r2);
+    } else if (W <= 16) {
+      uint32_t p[W];
+      planes_from_lds<W>(lds32, lane, p);
+      sel = pred_in_from_regs<W>(p, args.consts, args.n_consts);
+    } else {
+      sel = pred_in_from_lds(lds32, W, lane, args.consts, args.n_consts);
+    }
+    uint32_t bm = bitrev32(sel);
+    const int64_t valid = n_sub - ((b0 + (int64_t)k * kBlocksPerTile) * 64 + (int64_t)lane * 32);
+    if (valid < 32) bm = valid <= 0 ? 0u : (bm & ((1u << valid) - 1u));  // data rows that do not exist select nothing
+    seg[k * 64 + lane] = bm;
+    wave_lds_fence();  // the plane image is reused by the next sub-tile; the segment is read below
+  }
+
+  // deposit: the window of a word = three segment dwords from its rank on
+#pragma unroll
+  for (int r2 = 0; r2 < kExpRounds; ++r2) {
+    const int64_t w0 = first + r2 * 128 + 2 * lane;
+    u64 res[2];
+    uint32_t rel = lead + excl[r2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const uint32_t mlo = (uint32_t)m[r2][e], mhi = (uint32_t)(m[r2][e] >> 32);
+      uint32_t lo = 0, src_hi = 0;
+      if (m[r2][e] != 0ull) {  // (a word without NOT-NULL rows may sit past the evaluated blocks)
+        const uint32_t i0 = rel >> 5, sh = rel & 31u;
+        const uint32_t d0 = seg[i0], d1 = seg[i0 + 1], d2 = seg[i0 + 2];
+        lo = __builtin_amdgcn_alignbit(d1, d0, sh);
+        const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+        const uint32_t pcl = (uint32_t)__builtin_popcount(mlo);
+        src_hi = pcl == 32u ? hi : __builtin_amdgcn_alignbit(hi, lo, pcl);
+      }
+      res[e] = (u64)deposit32(lo, mlo, lut) | ((u64)deposit32(src_hi, mhi, lut) << 32);
+      rel += (uint32_t)__builtin_popcountll(m[r2][e]);
+    }
+    if (w0 + 1 < n_words) {
+      u32x4* dst = reinterpret_cast<u32x4*>(out + w0);
+      if (args.combine != 0) {  // wave-uniform
+        const u32x4 old = *dst;
+        const u64 o0 = ((u64)old.y << 32) | old.x, o1 = ((u64)old.w << 32) | old.z;
+        res[0] = args.combine == 1 ? (res[0] & o0) : (res[0] | o0);
+        res[1] = args.combine == 1 ? (res[1] & o1) : (res[1] | o1);
+      }
+      const u32x4 t = {(uint32_t)res[0], (uint32_t)(res[0] >> 32), (uint32_t)res[1], (uint32_t)(res[1] >> 32)};
+      IPS_STREAM_STORE16(dst, t);
+    } else if (w0 < n_words) {
+      if (args.combine != 0) res[0] = args.combine == 1 ? (res[0] & out[w0]) : (res[0] | out[w0]);
+      out[w0] = res[0];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // w = 32, single comparison, early pruning.  A block of width 32 is two 128-byte lines: planes
 // 31..16 in the second, 15..0 in the first.  The MSB->LSB recurrence only needs the low planes for
 // rows that are still EQUAL to the constant after the high ones -- on a column that uses its 32

@@ -162,6 +162,55 @@ static ips_status launch_pred_w(const uint64_t* enc, int64_t n_rows, const PredA
   return launch_pred_wk<W, kPredSingle>(enc, n_rows, args, bitmap32, s);
 }
 
+// The fused nullable leaf (fle_leaf_kernel): one workgroup per quarter rank tile of output words.
+// *taken = false (nothing launched) for the shapes that keep predicate and expand as separate
+// launches: IN lists long enough for the membership table, comparisons at w = 32.
+template <int W>
+static ips_status launch_leaf_w(const uint64_t* enc, int64_t n_sub, const PredArgs& args, uint64_t* out,
+                                bool* taken, hipStream_t s) {
+  const int64_t n_words = (args.aux_rows + 63) / 64;
+  const dim3 grid((unsigned)((n_words + kExpWordsPerBlock - 1) / kExpWordsPerBlock));
+  unsigned long long* o = reinterpret_cast<unsigned long long*>(out);
+  *taken = true;
+  if constexpr (W == 32) {
+    // comparisons of full-width columns read half the planes with the early-pruning predicate
+    // kernel (2^28 rows, 10 % NULL: 133 us as predicate + expand, 186 us here)
+    static const bool early = getenv("IPS_NO_EARLY_PRUNE") == nullptr;
+    if (early && args.op != 5) {
+      *taken = false;
+      return IPS_OK;
+    }
+  }
+  if (args.join != 0) {
+    hipLaunchKernelGGL((fle_leaf_kernel<W, kPredPair>), grid, dim3(kThreads), 0, s, enc, n_sub, args, o);
+  } else if (args.op == 5) {
+    if constexpr (W <= 16) {
+      if (args.n_consts >= in_table_min_pred(W)) {
+        *taken = false;
+        return IPS_OK;
+      }
+    }
+    hipLaunchKernelGGL((fle_leaf_kernel<W, kPredInList>), grid, dim3(kThreads), 0, s, enc, n_sub, args, o);
+  } else {
+    hipLaunchKernelGGL((fle_leaf_kernel<W, kPredSingle>), grid, dim3(kThreads), 0, s, enc, n_sub, args, o);
+  }
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+ips_status IPS_CAT(launch_fle_leaf_part_, IPS_PART)(int w, const uint64_t* enc, int64_t n_sub,
+                                                    const PredArgs& args, uint64_t* out, bool* taken,
+                                                    hipStream_t s) {
+#define IPS_CASE(N) \
+  case IPS_WLO + N: return launch_leaf_w<IPS_WLO + N>(enc, n_sub, args, out, taken, s);
+  switch (w) {
+    IPS_CASE(0) IPS_CASE(1) IPS_CASE(2) IPS_CASE(3) IPS_CASE(4) IPS_CASE(5) IPS_CASE(6) IPS_CASE(7)
+  }
+#undef IPS_CASE
+  set_error("bit width %d outside part starting at %d", w, IPS_WLO);
+  return IPS_ERR_INVALID_ARG;
+}
+
 ips_status IPS_CAT(launch_fle_pred_part_, IPS_PART)(int w, const uint64_t* enc, int64_t n_rows,
                                                     const PredArgs& args, uint32_t* bitmap32,
                                                     hipStream_t s) {

@@ -71,6 +71,11 @@ ips_status launch_rank_tile_counts(int root_kind, const uint64_t* root, int64_t 
 ips_status launch_expand(int root_kind, const uint64_t* root, const uint64_t* sub, int64_t n_rows,
                          int64_t n_sub_bits, const uint32_t* tile_counts, uint64_t* out,
                          int combine, hipStream_t s);
+bool fused_leaf_enabled();
+ips_status launch_fle_leaf(int w, int root_kind, const uint64_t* root, int64_t n_rows,
+                           const uint32_t* tile_counts, const uint64_t* enc, int64_t n_sub,
+                           const PredArgs& pred, uint64_t* out, int combine, bool* taken,
+                           hipStream_t s);
 ips_status launch_bitmap_fill(uint64_t* a, int64_t n_rows, int value, hipStream_t s);
 ips_status launch_compress(int mask_kind, const uint64_t* mask, int src_kind, const uint64_t* src,
                            int64_t n_rows, uint64_t* out, int64_t* n_out, uint32_t* tile_counts,

@@ -537,18 +537,25 @@ ips_status emit_item(const ChainItem& it, int combine, const ips_column* cols, i
       NullableCol& nc = nctx.col[it.a->column];
       const int64_t n_sub = c.n_data_rows < n_rows ? c.n_data_rows : n_rows;
       args.combine = 0;
+      const uint64_t* enc = reinterpret_cast<const uint64_t*>(c.d_data);
+      const bool fused = fused_leaf_enabled() && n_sub > 0;
       if (!nc.counted) {
         nc.counted = true;
-        if (n_sub > 0) {
+        if (n_sub > 0 && !fused) {
           attach_rank_counts(&args, nc.root_kind, nc.root, n_rows, nc.tile_counts);
         } else {
           ips_status st = launch_rank_tile_counts(nc.root_kind, nc.root, n_rows, nc.tile_counts, s);
           if (st != IPS_OK) return st;
         }
       }
+      if (fused) {  // predicate + IntersectBitset + combine in one kernel
+        bool taken = false;
+        ips_status st = launch_fle_leaf(c.bit_width, nc.root_kind, nc.root, n_rows, nc.tile_counts, enc,
+                                        n_sub, args, d_bitmap, combine, &taken, s);
+        if (st != IPS_OK || taken) return st;
+      }
       if (n_sub > 0) {
-        ips_status st = launch_fle_pred(c.bit_width, reinterpret_cast<const uint64_t*>(c.d_data), n_sub,
-                                        args, reinterpret_cast<uint32_t*>(nctx.sub), s);
+        ips_status st = launch_fle_pred(c.bit_width, enc, n_sub, args, reinterpret_cast<uint32_t*>(nctx.sub), s);
         if (st != IPS_OK) return st;
       }
       return launch_expand(nc.root_kind, nc.root, nctx.sub, n_rows, n_sub, nc.tile_counts, d_bitmap,

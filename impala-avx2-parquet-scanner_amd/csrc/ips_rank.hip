@@ -28,21 +28,6 @@ __global__ __launch_bounds__(kRankThreads) void rank_tile_counts_kernel(
   rank_tile_counts_body<ROOT, ZERO>(root, n_rows, tile_counts, blockIdx.x, gridDim.x, zero_out);
 }
 
-// pdep of the low popcount(mask) bits of src into the set positions of mask, four mask bits at a
-// time: table[mask4 << 4 | src4].  Per nibble: two bit-field extracts (the second at the running
-// rank of the nibble inside its 32-bit half), one table read, one shift-or, one popcount-add.
-__device__ __forceinline__ uint32_t deposit32(uint32_t sh, uint32_t mh, const uint8_t* __restrict__ lut) {
-  uint32_t o = 0, rank = 0;
-#pragma unroll
-  for (int n = 0; n < 8; ++n) {
-    const uint32_t m4 = (mh >> (4 * n)) & 15u;
-    const uint32_t s4 = (sh >> rank) & 15u;  // rank <= 28
-    o |= (uint32_t)lut[(m4 << 4) | s4] << (4 * n);
-    rank += (uint32_t)__builtin_popcount(m4);
-  }
-  return o;
-}
-
 __device__ __forceinline__ u64 deposit64(u64 src, u64 mask, const uint8_t* __restrict__ lut) {
   const uint32_t lo = deposit32((uint32_t)src, (uint32_t)mask, lut);
   const uint32_t hi = deposit32((uint32_t)(src >> __builtin_popcount((uint32_t)mask)), (uint32_t)(mask >> 32), lut);
@@ -55,15 +40,7 @@ struct NibbleLut { uint8_t v[256]; };
 constexpr NibbleLut make_deposit_lut() {
   NibbleLut t{};
   for (uint32_t i = 0; i < 256; ++i) {
-    const uint32_t m = i >> 4, v = i & 15u;
-    uint32_t d = 0, j = 0;
-    for (uint32_t bit = 0; bit < 4; ++bit) {
-      if (m & (1u << bit)) {
-        if (v & (1u << j)) d |= 1u << bit;
-        ++j;
-      }
-    }
-    t.v[i] = (uint8_t)d;
+    t.v[i] = (uint8_t)deposit_lut_entry(i);
   }
   return t;
 }

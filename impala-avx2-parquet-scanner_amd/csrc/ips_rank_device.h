@@ -84,6 +84,35 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
   return __builtin_amdgcn_readlane(wave_inclusive_scan(x), 63);
 }
 
+// ---- deposit (pdep) through a 256-entry nibble table in LDS -----------------------------------
+// pdep of the low popcount(mask) bits of src into the set positions of mask, four mask bits at a
+// time: table[mask4 << 4 | src4].  Per nibble: two bit-field extracts (the second at the running
+// rank of the nibble inside its 32-bit half), one table read, one shift-or, one popcount-add.
+__device__ __forceinline__ uint32_t deposit32(uint32_t sh, uint32_t mh, const uint8_t* __restrict__ lut) {
+  uint32_t o = 0, rank = 0;
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    const uint32_t m4 = (mh >> (4 * n)) & 15u;
+    const uint32_t s4 = (sh >> rank) & 15u;  // rank <= 28
+    o |= (uint32_t)lut[(m4 << 4) | s4] << (4 * n);
+    rank += (uint32_t)__builtin_popcount(m4);
+  }
+  return o;
+}
+
+// entry i = (mask4 << 4 | src4) of the deposit table
+constexpr uint32_t deposit_lut_entry(uint32_t i) {
+  const uint32_t m = i >> 4, v = i & 15u;
+  uint32_t d = 0, j = 0;
+  for (uint32_t bit = 0; bit < 4; ++bit) {
+    if (m & (1u << bit)) {
+      if (v & (1u << j)) d |= 1u << bit;
+      ++j;
+    }
+  }
+  return d;
+}
+
 // tile_counts[t] = set root bits of tile t; tile_counts[tiles + 4 t + w] = those of its wave w (the
 // quarter tiles expand_kernel works on).  One workgroup of 256 threads per tile.
 // ZERO: also clears the words of 'zero_out' that belong to the tile (the compress output must start

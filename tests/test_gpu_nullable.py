@@ -58,6 +58,45 @@ def test_nullable_leaf_vs_oracle(capi, O, n, null_frac):
     assert np.array_equal(got, expect)
 
 
+@pytest.mark.parametrize("bw", list(range(1, 33)))
+def test_nullable_leaf_every_width(capi, O, bw):
+    """Every code width through the one-pass leaf (fle_leaf_kernel: comparisons, short IN lists,
+    pairs via the program) and through the routes it hands back (long IN lists -> membership table,
+    w = 32 comparisons -> early-pruning predicate + expand); ragged row count, a data buffer that is
+    not a whole number of blocks, output poisoned first."""
+    rng = np.random.default_rng(1000 + bw)
+    n = 150001 + 64 * bw
+    is_set = rng.random(n) >= 0.3
+    is_set[70000:90000] = False            # a stretch of NULLs wider than a wave's 16384 rows
+    is_set[100000:120000] = True
+    k = int(is_set.sum())
+    hi = (1 << bw) - 1
+    vals = rng.integers(0, hi + 1, k, dtype=np.uint64).astype(np.uint32)
+    defs, enc = O.fle_encode(is_set.astype(np.uint32), 1), O.fle_encode(vals, bw)
+    d_defs, d_enc = dev_words(defs), dev_words(enc)
+    c = int(vals[k // 3])
+    long_list = [int(v) for v in vals[:40]]
+    out = torch.empty((n + 63) // 64, dtype=torch.int64, device="cuda")
+    for op, consts in ((O.OP_LT, c), (O.OP_GE, c), (O.OP_EQ, c), (O.OP_IN, [c, 0, hi]), (O.OP_IN, long_list)):
+        out.fill_(-1)
+        capi.fle_pred_nullable(d_defs, 1, 1, n, d_enc, k, bw, op, consts, bitmap=out)
+        exp = oracle_leaf(O, defs, 1, 1, n, enc, k, bw, op, consts)
+        assert np.array_equal(words(out), exp), (bw, op)
+    # BETWEEN in one pass, AND-ed / OR-ed into a bitmap of another column (combine modes)
+    other = rng.integers(0, 16, n).astype(np.uint32)
+    d_other = dev_words(O.fle_encode(other, 4))   # (the column descriptor holds the pointer only)
+    cols = [capi.fle_column(d_other, 4), capi.nullable_fle_column(d_defs, 1, 1, d_enc, bw, k)]
+    full = np.full(n, -1, np.int64)
+    full[is_set] = vals
+    lo, up = sorted((c, int(vals[k // 2])))
+    between = (full >= lo) & (full <= up)
+    L, AND, OR = capi.leaf, capi.and_node, capi.or_node
+    got = bits_of(words(capi.eval_program([L(0, O.OP_LT, 9), L(1, O.OP_GE, lo), L(1, O.OP_LE, up), AND(), AND()], cols, n)), n)
+    assert np.array_equal(got, (other < 9) & between)
+    got = bits_of(words(capi.eval_program([L(0, O.OP_LT, 3), L(1, O.OP_GE, lo), L(1, O.OP_LE, up), AND(), OR()], cols, n)), n)
+    assert np.array_equal(got, (other < 3) | between)
+
+
 def test_nullable_leaf_wider_definition_levels(capi, O):
     """max_def_level 2 (a nested OPTIONAL): levels are 2 bits wide, NOT NULL <=> level == 2."""
     rng = np.random.default_rng(5)
