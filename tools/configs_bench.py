@@ -55,6 +55,21 @@ def main():
 
     n = args.rows
     W = (n + 63) // 64
+    # ---- configs[1] beyond its quoted point: the fused FLE scan over the selectivity sweep ----------
+    for bw in (32, 12):
+        vals = capi.synth_u32(0x5EED0001, n, bw)
+        enc = capi.fle_encode(vals, bw)
+        outs = capi.alloc_scan_outputs(n, dev)
+        for sel in (0.01, 0.10, 0.50, 1.0):
+            c = min(int(sel * (1 << bw)), (1 << bw) - 1)
+            op = capi.OP_LT if sel < 1.0 else capi.OP_LE
+            f = lambda: capi.fle_scan(enc, n, bw, op, c, outputs=outs)
+            tmin, tmed = timeit(f)
+            nsel = int(outs[2].to(torch.int64).sum().item())
+            exp = int(((vals.to(torch.int64) & 0xFFFFFFFF) < c).sum().item()) if sel < 1.0 else n
+            report(f"configs[1] FLE w={bw} fused scan LT sel={sel}", n, W * 8 * (bw + 1) + 4 * nsel, tmin, tmed,
+                   nsel == exp and capi.bitmap_count(outs[0], n) == exp, {"selectivity": round(nsel / n, 4)})
+        del vals, enc, outs
     # ---- configs[2]: int64 -- PLAIN 8 B/row and dictionary D=4096 (w=12); BETWEEN + And(Gt,Lt) ---
     rng = np.random.default_rng(3)
     x = capi.synth_u32(0x5EED0003, n, 32).to(torch.int64) & 0xFFFFFFFF

@@ -146,7 +146,7 @@ del is_set
 venc = capi.fle_encode(capi.synth_u32(0x5EED0D2, k, 12), 12)
 n_data = ((k + 63) // 64) * 64
 wsn = capi.nullable_workspace(n, dev)
-run("nullable leaf w=12, 10% NULL (pred + expand)", "expand_kernel<1, 0>", W * 16 + n_data // 64 * 96,
+run("nullable leaf w=12, 10% NULL (counts + leaf)", "fle_leaf_kernel<12, 0>", W * 16 + n_data // 64 * 96,
     lambda: capi.fle_pred_nullable(defs, 1, 1, n, venc, n_data, 12, capi.OP_LT, 409, bitmap=bm, workspace=wsn))
 del defs, venc, wsn
 

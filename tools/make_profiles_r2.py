@@ -136,7 +136,7 @@ with open(os.path.join(dst, f"{tag}_kernel_tour.md"), "w") as f:
     fix = {"fle_pred w=32 BETWEEN": "fle_pred32_early_kernel<32, true>", "fle_pred w=16 BETWEEN": "fle_pred_w_kernel<16, 1>",
            "fle_pred w=8 BETWEEN": "fle_pred_w_kernel<8, 1>", "fle_pred w=16 LT": "fle_pred_w_kernel<16, 0>",
            "fle_pred w=8 LT": "fle_pred_w_kernel<8, 0>", "fle_pred w=32 LT": "fle_pred32_early_kernel<32, false>",
-           "nullable leaf w=12, 10% NULL (pred + expand)": "expand_kernel<1, 0>", "bitmap_expand (root 50%)": "expand_kernel<0, 0>",
+           "nullable leaf w=12, 10% NULL (counts + leaf)": "fle_leaf_kernel<12, 0>", "bitmap_expand (root 50%)": "expand_kernel<0, 0>",
            "Q6 conjunction, 3 columns (3 launches)": "fle_pred_w_kernel<12, 1>"}
     for t in tour:
         t["kernel"] = fix.get(t["op"], t["kernel"])
@@ -160,3 +160,15 @@ with open(os.path.join(dst, f"{tag}_kernel_tour.md"), "w") as f:
                 f"{valu and round(valu)} / {ldsi and round(ldsi, 1)} | {conf is not None and round(conf, 2)} |\n" if d else
                 f"| {t['op']} | ? | 0 | - | {t['us_event']} | {t['bytes']/1e6:.0f} | {gbs:.0f} | {gbs/80:.1f} | - | - | - |\n")
 print("summaries:", sorted(os.listdir(dst)))
+
+# ---- 3. BASELINE configs[1..4] with their sweeps (tools/configs_bench.py) ------------------------
+cb = os.path.join(src, "configs_bench.jsonl")
+if os.path.exists(cb):
+    recs = [json.loads(l) for l in open(cb) if l.startswith("{")]
+    with open(os.path.join(dst, f"{tag}_configs_bench.md"), "w") as f:
+        f.write(f"# {tag}: BASELINE configs[1..4] and their selectivity sweeps (tools/configs_bench.py, HIP-event timing, "
+                "inputs resident in HBM; `check` = popcount / selected-row count against a torch model of the predicate)\n\n")
+        f.write("| config | rows | algorithmic MB | us (median) | us (min) | GB/s | % of 8 TB/s | G rows/s | check |\n|---|---|---|---|---|---|---|---|---|\n")
+        for r in recs:
+            f.write(f"| {r['config']} | {r['rows']} | {r['algorithmic_bytes']/1e6:.0f} | {r['us_med']} | {r['us_min']} | "
+                    f"{r['GBps_med']:.0f} | {r['GBps_med']/80:.1f} | {r['Grows_per_s_med']} | {r['check']} |\n")

@@ -17,6 +17,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/tour_fetch
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/tour_write -- python3 $R/tools/kernel_tour.py > $OUT/tour_write.jsonl 2> $OUT/tour_write.log
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $OUT/tour_sq -- python3 $R/tools/kernel_tour.py > $OUT/tour_sq.jsonl 2> $OUT/tour_sq.log
 python3 $R/tools/kernel_tour.py > $OUT/tour_plain.jsonl 2> $OUT/tour_plain.log
+# 3. BASELINE configs[1..4] with their selectivity sweeps (event timing, property checks)
+python3 $R/tools/configs_bench.py > $OUT/configs_bench.jsonl 2> $OUT/configs_bench.log
 # condense on the box (the raw csv files are too large to travel): summaries only
 cd $R
 python3 tools/make_profiles_r2.py > $OUT/make_profiles.log 2>&1
