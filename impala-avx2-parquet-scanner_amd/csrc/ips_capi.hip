@@ -103,7 +103,9 @@ int grid_for_tiles(const void* kernel, int64_t tiles) {
   ips_status launch_fle_scan_pages_part_##P(int, const PageBatch&, int, int64_t,                \
                                             const PredArgs&, hipStream_t);                      \
   ips_status launch_fle_leaf_part_##P(int, const uint64_t*, int64_t, const PredArgs&, uint64_t*, \
-                                      bool*, hipStream_t);
+                                      bool*, hipStream_t);                                       \
+  ips_status launch_fle_selnull_part_##P(int, int, const uint64_t*, int64_t, const SelNullArgs&,  \
+                                         void*, const void*, uint32_t, int64_t*, hipStream_t);
 IPS_DECL_PARTS(a) IPS_DECL_PARTS(b) IPS_DECL_PARTS(c) IPS_DECL_PARTS(d)
 
 ips_status launch_bitmap_binop(int op, uint64_t* a, const uint64_t* b, int64_t n_words, hipStream_t s);
@@ -184,6 +186,15 @@ ips_status launch_fle_leaf(int w, int root_kind, const uint64_t* root, int64_t n
   if (w <= 16) return launch_fle_leaf_part_b(w, enc, n_sub, args, out, taken, s);
   if (w <= 24) return launch_fle_leaf_part_c(w, enc, n_sub, args, out, taken, s);
   return launch_fle_leaf_part_d(w, enc, n_sub, args, out, taken, s);
+}
+
+ips_status launch_fle_selnull(int w, int gather, const uint64_t* enc, int64_t n_data, const SelNullArgs& a,
+                              void* dense, const void* dict, uint32_t dict_entries, int64_t* n_values,
+                              hipStream_t s) {
+  if (w <= 8) return launch_fle_selnull_part_a(w, gather, enc, n_data, a, dense, dict, dict_entries, n_values, s);
+  if (w <= 16) return launch_fle_selnull_part_b(w, gather, enc, n_data, a, dense, dict, dict_entries, n_values, s);
+  if (w <= 24) return launch_fle_selnull_part_c(w, gather, enc, n_data, a, dense, dict, dict_entries, n_values, s);
+  return launch_fle_selnull_part_d(w, gather, enc, n_data, a, dense, dict, dict_entries, n_values, s);
 }
 
 ips_status launch_fle_encode(int w, int in_width, const void* values, int64_t n_rows,
@@ -844,7 +855,9 @@ ips_status ips_dict_select(const ips_dict* dict, const void* d_codes_enc, int64_
 // ---- OPTIONAL column: late materialisation in one call ---------------------------------------
 namespace {
 struct SelNullWs {
-  uint32_t* rank;        // tile counts (used by one compress at a time)
+  uint32_t* rank;        // tile counts (used by one compress at a time; one-pass route: NOT-NULL rows)
+  uint32_t* rank_s;      // one-pass route: tile counts of the selection
+  uint32_t* rank_rs;     //                 and of the selected NOT-NULL rows
   uint64_t* nonnull;     // NOT-NULL bitmap when the levels are wider than a bit
   uint64_t* data_sel;    // the selection over the data rows
   uint8_t* batch_values; // per-batch values of the selected data rows
@@ -860,6 +873,8 @@ SelNullWs sel_null_ws(void* base, int64_t n_rows, int64_t n_data_rows, int value
   SelNullWs w;
   size_t off = 0;
   w.rank = reinterpret_cast<uint32_t*>(p + off); off += rank_workspace_bytes(n_rows);
+  w.rank_s = reinterpret_cast<uint32_t*>(p + off); off += rank_workspace_bytes(n_rows);
+  w.rank_rs = reinterpret_cast<uint32_t*>(p + off); off += rank_workspace_bytes(n_rows);
   w.nonnull = reinterpret_cast<uint64_t*>(p + off); off += bm;
   w.data_sel = reinterpret_cast<uint64_t*>(p + off); off += bm;
   w.batch_values = p + off; off += align256((size_t)nb * IPS_BATCH_ROWS * (size_t)value_width);
@@ -901,8 +916,35 @@ ips_status ips_dict_select_nullable(const ips_dict* dict, const void* d_def_leve
   nws.nonnull = w.nonnull;
   int root_kind = 0;
   const uint64_t* root = nullptr;
-  st = nullable_prepare_root(d_def_levels, def_bit_width, max_def_level, n_rows, nws, &root_kind, &root, s);
+  static const bool one_pass = getenv("IPS_SELECT_NULLABLE_STEPS") == nullptr;  // dev switch for A/B runs
+  st = nullable_prepare_root(d_def_levels, def_bit_width, max_def_level, n_rows, nws, &root_kind, &root, s,
+                             /*count_tiles=*/false);
   if (st != IPS_OK) return st;
+  if (one_pass) {
+    // counts of NOT-NULL / selected / selected NOT-NULL rows per rank tile (and the flag words
+    // cleared), then values: fle_select_nullable_kernel, then the NOT-NULL flag of every selected
+    // row (the NULL indicator bit, hdfs-parquet-scanner.cc:1022-1026) by the compress kernel on the
+    // selection's counts
+    st = launch_rank3_counts(root_kind, root, d_selection, n_rows, w.rank, w.rank_s, w.rank_rs, d_nonnull_flags, s);
+    if (st != IPS_OK) return st;
+    const int64_t n_data = n_data_rows < n_rows ? n_data_rows : n_rows;
+    if (n_data > 0) {
+      SelNullArgs a;
+      a.root = reinterpret_cast<const unsigned long long*>(root);
+      a.sel = reinterpret_cast<const unsigned long long*>(d_selection);
+      a.c_r = w.rank;
+      a.c_rs = w.rank_rs;
+      a.n_rows = n_rows;
+      a.root_kind = root_kind;
+      st = launch_fle_selnull(bit_width, dict ? dict->slot : 0, reinterpret_cast<const uint64_t*>(d_codes_enc), n_data,
+                              a, d_dense_values, dict ? dict->d_entries : nullptr, dict ? (uint32_t)dict->n : 0u,
+                              d_counts + 1, s);
+      if (st != IPS_OK) return st;
+    } else {
+      IPS_HIP_TRY(hipMemsetAsync(d_counts + 1, 0, 8, s));
+    }
+    return launch_compress_counted(0, d_selection, root_kind, root, n_rows, d_nonnull_flags, d_counts, w.rank_s, s);
+  }
   // 1. the selection over the DATA rows (the rows ReadValue decodes once ReadDefinitionLevel said
   //    non-NULL, hdfs-parquet-scanner.cc:1009-1014)
   st = launch_compress(root_kind, root, 0, d_selection, n_rows, w.data_sel, nullptr, w.rank, s);

@@ -817,6 +817,240 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_leaf_kerne
 }
 
 // ---------------------------------------------------------------------------------------------
+// Late materialisation of an OPTIONAL column in one pass (ReadValue(skip) over a whole selection,
+// hdfs-parquet-scanner.cc:1006-1038 + 927-979: ReadDefinitionLevel says which selected rows are
+// NULL and which data row a NOT-NULL one decodes).  A workgroup owns a quarter rank tile of ROWS
+// (1024 words; a wave 256 words = 16 384 rows).  From the three count tables of
+// rank3_counts_kernel the wave knows the data row of its first NOT-NULL row (R) and the dense
+// output index of its first selected NOT-NULL row (RS).  It extracts the selection at the
+// NOT-NULL positions (pext through the nibble table) into an LDS segment -- the selection over
+// its OWN data rows, which the three-launch route wrote to HBM as a bitmap over all data rows --
+// then walks the data sub-tiles that hold them: blocks without a selected row are not loaded,
+// of the others the selected rows go on an index list and are decoded one per lane straight from
+// the plane image (through the dictionary if there is one) into dense[RS index .. ), coalesced and
+// in row order.  No per-batch buffers, no compaction pass.
+// ---------------------------------------------------------------------------------------------
+struct SelNullArgs {
+  const unsigned long long* root;
+  const unsigned long long* sel;
+  const uint32_t* c_r;
+  const uint32_t* c_rs;
+  int64_t n_rows;
+  int32_t root_kind;
+};
+
+template <int W, int G>
+__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_select_nullable_kernel(
+    const uint64_t* __restrict__ enc, int64_t n_data, SelNullArgs a,
+    typename GatherT<G>::type* __restrict__ dense, const typename GatherT<G>::type* __restrict__ dict,
+    uint32_t dict_entries, int64_t* __restrict__ n_values) {
+  using GT = typename GatherT<G>::type;
+  constexpr int kRegionBytes = plane_tile_bytes(W);
+  constexpr int kSegWords64 = kLeafSegDwords / 2 + 2;  // the wave's data-row selection, <= 257 words used
+  constexpr uint32_t kListMax = 1024;                  // index-list window (entries of 16 bits)
+  __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kRegionBytes / 4];
+  __shared__ __attribute__((aligned(16))) u64 seg_all[kWavesPerBlock][kSegWords64];
+  __shared__ uint16_t list_all[kWavesPerBlock][kListMax];
+  __shared__ uint8_t lut[256];
+  __shared__ u64 part_r[kRankWaves], part_rs[kRankWaves];
+  __shared__ uint32_t tot_r[kRankWaves], tot_rs[kRankWaves];
+  constexpr int L = (16 * W + kWave - 1) / kWave;
+  const int lane = lane_id();
+  const int wave = wave_id();
+  uint32_t* lds32 = lds_all + wave * (kRegionBytes / 4);
+  u64* seg = seg_all[wave];
+  uint16_t* list = list_all[wave];
+  lut[threadIdx.x] = (uint8_t)extract_lut_entry(threadIdx.x);
+  for (int i = lane; i < kSegWords64; i += kWave) seg[i] = 0ull;
+
+  const u64* __restrict__ root = a.root;
+  const u64* __restrict__ sel = a.sel;
+  const int64_t n_rows = a.n_rows;
+  const int64_t n_words = (n_rows + 63) / 64;
+  const int64_t tiles = (n_words + kRankWordsPerTile - 1) / kRankWordsPerTile;
+  const int64_t first = (int64_t)blockIdx.x * kExpWordsPerBlock + wave * kExpWordsPerWave;
+  u64 m[kExpRounds][2], sv[kExpRounds][2];
+  if (a.root_kind == kRootLevels1) load_root<kRootLevels1, kExpRounds>(root, first, n_words, n_rows, lane, m);
+  else load_root<kRootBitmap, kExpRounds>(root, first, n_words, n_rows, lane, m);
+  load_root<kRootBitmap, kExpRounds>(sel, first, n_words, n_rows, lane, sv);
+
+  // ranks of the workgroup's first word in R and RS (see expand_kernel)
+  const int64_t tile = (int64_t)blockIdx.x / kExpBlocksPerTile;
+  const int part_waves = (int)(blockIdx.x % kExpBlocksPerTile) * (kRankWaves / kExpBlocksPerTile);
+  uint32_t before_r = 0, before_rs = 0;
+  for (int64_t i = threadIdx.x; i < tile; i += kRankThreads) {
+    before_r += a.c_r[i];
+    before_rs += a.c_rs[i];
+  }
+  if ((int)threadIdx.x < part_waves) {
+    before_r += a.c_r[tiles + tile * kRankWaves + threadIdx.x];
+    before_rs += a.c_rs[tiles + tile * kRankWaves + threadIdx.x];
+  }
+  {
+    const uint32_t lo = wave_sum(before_r & 0xFFFFu), hi = wave_sum(before_r >> 16);
+    const uint32_t lo2 = wave_sum(before_rs & 0xFFFFu), hi2 = wave_sum(before_rs >> 16);
+    if (lane == 0) {
+      part_r[wave] = (u64)lo + ((u64)hi << 16);
+      part_rs[wave] = (u64)lo2 + ((u64)hi2 << 16);
+    }
+  }
+  uint32_t excl[kExpRounds];
+  uint32_t run_r = 0, mine_rs = 0;
+#pragma unroll
+  for (int r = 0; r < kExpRounds; ++r) {
+    const uint32_t c = (uint32_t)(__builtin_popcountll(m[r][0]) + __builtin_popcountll(m[r][1]));
+    const uint32_t incl = wave_inclusive_scan(c);
+    excl[r] = run_r + incl - c;
+    run_r += __builtin_amdgcn_readlane(incl, 63);
+    mine_rs += (uint32_t)(__builtin_popcountll(m[r][0] & sv[r][0]) + __builtin_popcountll(m[r][1] & sv[r][1]));
+  }
+  const uint32_t run_rs = wave_sum(mine_rs);
+  if (lane == 0) {
+    tot_r[wave] = run_r;
+    tot_rs[wave] = run_rs;
+  }
+  __syncthreads();
+  u64 base_r = part_r[0] + part_r[1] + part_r[2] + part_r[3];
+  u64 base_rs = part_rs[0] + part_rs[1] + part_rs[2] + part_rs[3];
+  for (int w = 0; w < wave; ++w) {
+    base_r += tot_r[w];
+    base_rs += tot_rs[w];
+  }
+
+  // the selection over the wave's data rows: bit (lead + rank inside the wave) of the segment
+  const uint32_t lead = (uint32_t)(base_r & 63);
+#pragma unroll
+  for (int r = 0; r < kExpRounds; ++r) {
+    uint32_t o = lead + excl[r];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const u64 mk = m[r][e];
+      const uint32_t pc = (uint32_t)__builtin_popcountll(mk);
+      if ((sv[r][e] & mk) != 0ull) {  // (a word without a selected NOT-NULL row adds nothing)
+        const u64 bits = extract64(sv[r][e], mk, lut);
+        const uint32_t sh = o & 63u;
+        __hip_atomic_fetch_or(&seg[o >> 6], bits << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (sh && (bits >> (64 - sh)))
+          __hip_atomic_fetch_or(&seg[(o >> 6) + 1], bits >> (64 - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+      o += pc;
+    }
+  }
+  wave_lds_fence();
+  const uint32_t* seg32 = reinterpret_cast<const uint32_t*>(seg);
+
+  // data blocks [b0, b0 + n_blk) hold the wave's data rows; dword (k * 64 + lane) of the segment is
+  // this lane's half-block of sub-tile k
+  const int64_t b0 = (int64_t)(base_r >> 6);
+  const int n_blk = run_r ? (int)((lead + run_r + 63u) >> 6) : 0;
+  const int n_st = (n_blk + kBlocksPerTile - 1) / kBlocksPerTile;
+  const int64_t total_words = ((n_data + 63) / 64) * W;
+  auto dword_of = [&](int k) -> uint32_t {  // selected rows of the half-block that exist in the data buffer
+    if (k >= n_st) return 0u;
+    uint32_t bm = seg32[k * 64 + lane];
+    const int64_t valid = n_data - ((b0 + (int64_t)k * kBlocksPerTile) * 64 + (int64_t)lane * 32);
+    if (valid < 32) bm = valid <= 0 ? 0u : (bm & ((1u << valid) - 1u));
+    return bm;
+  };
+  // per 16-byte chunk of a sub-tile that this lane moves: the bits of the "needed blocks" mask
+  // that decide whether it is loaded, and its place in the LDS image -- the same for every sub-tile
+  uint32_t need_sh[L];  // 2 * first block | 2 * second block << 8; 0xFFFF: no such chunk
+  int img_dw[L];
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    const int c = i * kWave + lane;
+    const int blk0 = (2 * c) / W, blk1 = (2 * c + 1) / W;
+    need_sh[i] = c < 16 * W ? (uint32_t)(2 * blk0) | ((uint32_t)(2 * blk1) << 8) : 0xFFFFu;
+    // (odd W: block stride W, the image is linear; even W: both words belong to one block)
+    img_dw[i] = 2 * (blk0 * (W | 1) + (2 * c - blk0 * W));
+  }
+  auto load = [&](int k, uint32_t bm, u32x4 (&r)[L]) {  // only the blocks that hold a selected row
+    const uint64_t any = __builtin_amdgcn_ballot_w64(bm != 0u);  // bit l <-> half-block of lane l
+    if (k >= n_st || any == 0ull) return;                        // (wave-uniform)
+    const uint64_t need = any | (any >> 1);                      // bit 2b <-> block b
+    const int64_t w0 = (b0 + (int64_t)k * kBlocksPerTile) * W;
+    int64_t left = total_words - w0;
+    left = left < 0 ? 0 : (left > kBlocksPerTile * W ? kBlocksPerTile * W : left);
+    const uint64_t* bp = left > 0 ? enc + w0 : enc;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(bp), 0, (int)(left * 8), kBufferRsrcDword3);
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      if (need_sh[i] != 0xFFFFu && (((need >> (need_sh[i] & 63u)) | (need >> (need_sh[i] >> 8))) & 1ull))
+        r[i] = buffer_load16<true>(rsrc, (uint32_t)(i * kWave + lane) * 16u);
+    }
+  };
+  auto to_lds = [&](const u32x4 (&r)[L]) {
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      if (need_sh[i] != 0xFFFFu) {
+        const u32x2 lo = {r[i].x, r[i].y}, hi = {r[i].z, r[i].w};
+        *reinterpret_cast<u32x2*>(lds32 + img_dw[i]) = lo;
+        *reinterpret_cast<u32x2*>(lds32 + img_dw[i] + 2) = hi;
+      }
+    }
+  };
+  u64 out_pos = base_rs;  // dense index of the wave's next value
+  // sub-tile k: its bytes are in r (if any row is selected); r is refilled for sub-tile k + 2 as
+  // soon as it has been copied to LDS -- two sub-tiles of a wave are in flight, the chain of nine
+  // dependent steps per wave is what bounds this kernel
+  auto step = [&](int k, u32x4 (&r)[L], uint32_t bm, uint32_t bm_ahead) {
+    const uint32_t cnt = (uint32_t)__builtin_popcount(bm);
+    const uint32_t incl = wave_inclusive_scan(cnt);
+    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    if (total != 0u) to_lds(r);  // wave-uniform
+    load(k + 2, bm_ahead, r);
+    if (total == 0u) return;
+    // index list, in windows of kListMax: entry e of the sub-tile = (half-block << 5 | row) of its
+    // e-th selected row; then lane l decodes entries l, l + 64, ... straight from the plane image
+    // (one bit per plane: 2 ops) and stores them side by side -- nothing is transposed for the
+    // rows that are not selected, and the output leaves coalesced whatever its alignment
+    uint32_t mm = bm;
+    uint32_t idx = incl - cnt;  // sub-tile index of the lane's next entry
+    GT* dst = dense + out_pos;
+    for (uint32_t win0 = 0; win0 < total; win0 += kListMax) {
+      while (mm != 0u && idx < win0 + kListMax) {
+        list[idx - win0] = (uint16_t)((uint32_t)lane << 5 | (uint32_t)__builtin_ctz(mm));
+        mm &= mm - 1u;
+        ++idx;
+      }
+      wave_lds_fence();  // the list, and (first window) the plane image
+      const uint32_t n_win = total - win0 < kListMax ? total - win0 : kListMax;
+      for (uint32_t e = lane; e < n_win; e += kWave) {
+        const uint32_t entry = list[e];
+        const uint32_t h = entry >> 5, sh = 31u - (entry & 31u);
+        const uint32_t* pl = lds32 + 2 * ((h >> 1) * (W | 1)) + (1 - (h & 1));
+        uint32_t val = 0;
+#pragma unroll
+        for (int b = 0; b < W; ++b) val |= ((pl[2 * b] >> sh) & 1u) << b;
+        if (G == 0) dst[win0 + e] = (GT)val;
+        else if (val < dict_entries) dst[win0 + e] = dict[val];
+      }
+      wave_lds_fence();  // the list is rewritten by the next window, the image by the next sub-tile
+    }
+    out_pos += total;
+  };
+  u32x4 ra[L], rb[L];
+  uint32_t bm0 = dword_of(0), bm1 = dword_of(1);
+  load(0, bm0, ra);
+  load(1, bm1, rb);
+  for (int k = 0; k < n_st; k += 2) {
+    const uint32_t bm2 = dword_of(k + 2), bm3 = dword_of(k + 3);
+    step(k, ra, bm0, bm2);
+    if (k + 1 < n_st) step(k + 1, rb, bm1, bm3);
+    bm0 = bm2;
+    bm1 = bm3;
+  }
+
+  // the number of values: the wave that holds the end of the data buffer knows it, else the last wave
+  if (n_values && lane == 0) {
+    const bool last = blockIdx.x == gridDim.x - 1 && wave == kRankWaves - 1;
+    const u64 nd = (u64)n_data;
+    if ((base_r <= nd && nd < base_r + run_r) || (last && nd >= base_r + run_r)) *n_values = (int64_t)out_pos;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // w = 32, single comparison, early pruning.  A block of width 32 is two 128-byte lines: planes
 // 31..16 in the second, 15..0 in the first.  The MSB->LSB recurrence only needs the low planes for
 // rows that are still EQUAL to the constant after the high ones -- on a column that uses its 32

@@ -211,6 +211,47 @@ ips_status IPS_CAT(launch_fle_leaf_part_, IPS_PART)(int w, const uint64_t* enc, 
   return IPS_ERR_INVALID_ARG;
 }
 
+// Late materialisation of an OPTIONAL column (fle_select_nullable_kernel): gather 0 = the FLE
+// values themselves (32-bit), 4 / 8 = through a dictionary of 4- / 8-byte entries (codes <= 16 bits).
+template <int W>
+static ips_status launch_selnull_w(int gather, const uint64_t* enc, int64_t n_data, const SelNullArgs& a,
+                                   void* dense, const void* dict, uint32_t dict_entries, int64_t* n_values,
+                                   hipStream_t s) {
+  const int64_t n_words = (a.n_rows + 63) / 64;
+  const dim3 grid((unsigned)((n_words + kExpWordsPerBlock - 1) / kExpWordsPerBlock));
+  if (gather == 0) {
+    hipLaunchKernelGGL((fle_select_nullable_kernel<W, 0>), grid, dim3(kThreads), 0, s, enc, n_data, a,
+                       reinterpret_cast<uint32_t*>(dense), (const uint32_t*)nullptr, 0u, n_values);
+  } else {
+    if constexpr (W <= 16) {
+      if (gather == 4)
+        hipLaunchKernelGGL((fle_select_nullable_kernel<W, 4>), grid, dim3(kThreads), 0, s, enc, n_data, a,
+                           reinterpret_cast<uint32_t*>(dense), reinterpret_cast<const uint32_t*>(dict), dict_entries, n_values);
+      else
+        hipLaunchKernelGGL((fle_select_nullable_kernel<W, 8>), grid, dim3(kThreads), 0, s, enc, n_data, a,
+                           reinterpret_cast<uint64_t*>(dense), reinterpret_cast<const uint64_t*>(dict), dict_entries, n_values);
+    } else {
+      set_error("dictionary codes wider than 16 bits");
+      return IPS_ERR_INVALID_ARG;
+    }
+  }
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+ips_status IPS_CAT(launch_fle_selnull_part_, IPS_PART)(int w, int gather, const uint64_t* enc, int64_t n_data,
+                                                       const SelNullArgs& a, void* dense, const void* dict,
+                                                       uint32_t dict_entries, int64_t* n_values, hipStream_t s) {
+#define IPS_CASE(N) \
+  case IPS_WLO + N: return launch_selnull_w<IPS_WLO + N>(gather, enc, n_data, a, dense, dict, dict_entries, n_values, s);
+  switch (w) {
+    IPS_CASE(0) IPS_CASE(1) IPS_CASE(2) IPS_CASE(3) IPS_CASE(4) IPS_CASE(5) IPS_CASE(6) IPS_CASE(7)
+  }
+#undef IPS_CASE
+  set_error("bit width %d outside part starting at %d", w, IPS_WLO);
+  return IPS_ERR_INVALID_ARG;
+}
+
 ips_status IPS_CAT(launch_fle_pred_part_, IPS_PART)(int w, const uint64_t* enc, int64_t n_rows,
                                                     const PredArgs& args, uint32_t* bitmap32,
                                                     hipStream_t s) {

@@ -77,6 +77,12 @@ ips_status launch_fle_leaf(int w, int root_kind, const uint64_t* root, int64_t n
                            const PredArgs& pred, uint64_t* out, int combine, bool* taken,
                            hipStream_t s);
 ips_status launch_bitmap_fill(uint64_t* a, int64_t n_rows, int value, hipStream_t s);
+ips_status launch_rank3_counts(int root_kind, const uint64_t* root, const uint64_t* sel, int64_t n_rows,
+                               uint32_t* c_r, uint32_t* c_s, uint32_t* c_rs, uint64_t* zero_out,
+                               hipStream_t s);
+ips_status launch_compress_counted(int mask_kind, const uint64_t* mask, int src_kind, const uint64_t* src,
+                                   int64_t n_rows, uint64_t* out, int64_t* n_out,
+                                   const uint32_t* tile_counts, hipStream_t s);
 ips_status launch_compress(int mask_kind, const uint64_t* mask, int src_kind, const uint64_t* src,
                            int64_t n_rows, uint64_t* out, int64_t* n_out, uint32_t* tile_counts,
                            hipStream_t s);

@@ -47,15 +47,7 @@ constexpr NibbleLut make_deposit_lut() {
 constexpr NibbleLut make_extract_lut() {
   NibbleLut t{};
   for (uint32_t i = 0; i < 256; ++i) {
-    const uint32_t m = i >> 4, v = i & 15u;
-    uint32_t e = 0, j = 0;
-    for (uint32_t bit = 0; bit < 4; ++bit) {
-      if (m & (1u << bit)) {
-        if (v & (1u << bit)) e |= 1u << j;
-        ++j;
-      }
-    }
-    t.v[i] = (uint8_t)e;
+    t.v[i] = (uint8_t)extract_lut_entry(i);
   }
   return t;
 }
@@ -266,26 +258,6 @@ ips_status launch_bitmap_expand(const uint64_t* root, const uint64_t* sub, int64
 // output was cleared by the counting pass).  Round 1 issued two global atomics per input word.
 __device__ __forceinline__ void extract_lut_init(uint8_t* lut) { lut[threadIdx.x] = kExtractLut.v[threadIdx.x]; }
 
-__device__ __forceinline__ u64 extract64(u64 src, u64 mask, const uint8_t* __restrict__ lut) {
-  u64 out = 0;
-  uint32_t pos = 0;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const uint32_t mh = (uint32_t)(mask >> (32 * h)), sh = (uint32_t)(src >> (32 * h));
-    uint32_t o = 0, rank = 0;
-#pragma unroll
-    for (int n = 0; n < 8; ++n) {
-      const uint32_t m4 = (mh >> (4 * n)) & 15u;
-      const uint32_t s4 = (sh >> (4 * n)) & 15u;
-      o |= (uint32_t)lut[(m4 << 4) | s4] << rank;  // rank <= 28, the piece has <= 4 bits
-      rank += (uint32_t)__builtin_popcount(m4);
-    }
-    out |= (u64)o << pos;
-    pos += rank;
-  }
-  return out;
-}
-
 // Like expand_kernel, a workgroup takes a quarter tile (four waves of 256 words): several
 // generations of workgroups per CU, 2 KiB of LDS segment per wave instead of 8.
 constexpr int kSegWords = kExpWordsPerWave + 2;  // a wave's output segment: <= 16384 bits + misalignment
@@ -414,6 +386,104 @@ ips_status launch_bitmap_compress(const uint64_t* mask, const uint64_t* src, int
                                   uint64_t* out, int64_t* n_out, void* workspace, hipStream_t s) {
   return launch_compress(kRootBitmap, mask, kRootBitmap, src, n_rows, out, n_out,
                          reinterpret_cast<uint32_t*>(workspace), s);
+}
+
+// ---- counts for the one-pass late materialisation of an OPTIONAL column ----------------------
+// Per rank tile and per wave quarter: NOT-NULL rows (R), selected rows (S) and selected NOT-NULL
+// rows (RS) in one pass over the two bitmaps; also clears the flag words of the tile (the flags
+// leave fle_select_nullable's compress step through atomics at the segment ends).
+template <int ROOT>
+__global__ __launch_bounds__(kRankThreads) void rank3_counts_kernel(
+    const u64* __restrict__ root, const u64* __restrict__ sel, int64_t n_rows,
+    uint32_t* __restrict__ c_r, uint32_t* __restrict__ c_s, uint32_t* __restrict__ c_rs,
+    u64* __restrict__ zero_out) {
+  __shared__ uint32_t wave_tot[3][kRankWaves];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int64_t tile = blockIdx.x, tiles = gridDim.x;
+  const int64_t n_words = (n_rows + 63) / 64;
+  const int64_t first = tile * kRankWordsPerTile + wave * kRankWordsPerWave;
+  uint32_t cr = 0, cs = 0, crs = 0;
+  if ((first + kRankWordsPerWave) * 64 <= n_rows) {  // whole words only: popcounts do not care about the bit order
+#pragma unroll
+    for (int r = 0; r < kRankRounds; ++r) {
+      const int64_t w0 = first + r * 128 + 2 * lane;
+      const u32x4 a = stream_load<true>(reinterpret_cast<const u32x4*>(root + w0));
+      const u32x4 b = stream_load<true>(reinterpret_cast<const u32x4*>(sel + w0));
+      u32x4 ar = a;
+      if (ROOT == kRootLevels1)  // level words are MSB first, 64 bits at a time
+        ar = u32x4{__builtin_bitreverse32(a.y), __builtin_bitreverse32(a.x), __builtin_bitreverse32(a.w), __builtin_bitreverse32(a.z)};
+      cr += __builtin_popcount(a.x) + __builtin_popcount(a.y) + __builtin_popcount(a.z) + __builtin_popcount(a.w);
+      cs += __builtin_popcount(b.x) + __builtin_popcount(b.y) + __builtin_popcount(b.z) + __builtin_popcount(b.w);
+      crs += __builtin_popcount(ar.x & b.x) + __builtin_popcount(ar.y & b.y) + __builtin_popcount(ar.z & b.z) + __builtin_popcount(ar.w & b.w);
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(zero_out + w0) = z;
+    }
+  } else {
+    for (int r = 0; r < kRankRounds; ++r) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int64_t w0 = first + r * 128 + 2 * lane + e;
+        if (w0 < n_words) {
+          const u64 m = root_mask<ROOT>(root[w0], w0, n_rows);
+          const u64 sv = root_mask<kRootBitmap>(sel[w0], w0, n_rows);
+          cr += (uint32_t)__builtin_popcountll(m);
+          cs += (uint32_t)__builtin_popcountll(sv);
+          crs += (uint32_t)__builtin_popcountll(m & sv);
+          zero_out[w0] = 0ull;
+        }
+      }
+    }
+  }
+  const uint32_t tr = wave_sum(cr), ts = wave_sum(cs), trs = wave_sum(crs);
+  if (lane == 0) {
+    wave_tot[0][wave] = tr;
+    wave_tot[1][wave] = ts;
+    wave_tot[2][wave] = trs;
+    c_r[tiles + tile * kRankWaves + wave] = tr;
+    c_s[tiles + tile * kRankWaves + wave] = ts;
+    c_rs[tiles + tile * kRankWaves + wave] = trs;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    uint32_t* dst = threadIdx.x == 0 ? c_r : threadIdx.x == 1 ? c_s : c_rs;
+    const uint32_t* w = wave_tot[threadIdx.x];
+    dst[tile] = w[0] + w[1] + w[2] + w[3];
+  }
+}
+
+ips_status launch_rank3_counts(int root_kind, const uint64_t* root, const uint64_t* sel, int64_t n_rows,
+                               uint32_t* c_r, uint32_t* c_s, uint32_t* c_rs, uint64_t* zero_out,
+                               hipStream_t s) {
+  const int64_t tiles = rank_tiles(n_rows);
+  if (tiles <= 0) return IPS_OK;
+  const u64* r = reinterpret_cast<const u64*>(root);
+  const u64* sv = reinterpret_cast<const u64*>(sel);
+  u64* z = reinterpret_cast<u64*>(zero_out);
+  if (root_kind == kRootLevels1)
+    hipLaunchKernelGGL((rank3_counts_kernel<kRootLevels1>), dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, sv, n_rows, c_r, c_s, c_rs, z);
+  else
+    hipLaunchKernelGGL((rank3_counts_kernel<kRootBitmap>), dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, sv, n_rows, c_r, c_s, c_rs, z);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+// compress with the mask's tile counts already in 'tile_counts' and 'out' already cleared
+ips_status launch_compress_counted(int mask_kind, const uint64_t* mask, int src_kind, const uint64_t* src,
+                                   int64_t n_rows, uint64_t* out, int64_t* n_out,
+                                   const uint32_t* tile_counts, hipStream_t s) {
+  const int64_t tiles = rank_tiles(n_rows);
+  if (tiles <= 0) {
+    if (n_out) IPS_HIP_TRY(hipMemsetAsync(n_out, 0, 8, s));
+    return IPS_OK;
+  }
+  const u64* mk = reinterpret_cast<const u64*>(mask);
+  const u64* sr = reinterpret_cast<const u64*>(src);
+  u64* o = reinterpret_cast<u64*>(out);
+  if (mask_kind == kRootLevels1) launch_compress_src<kRootLevels1>(src_kind, tiles, s, mk, sr, n_rows, tile_counts, o, n_out);
+  else launch_compress_src<kRootBitmap>(src_kind, tiles, s, mk, sr, n_rows, tile_counts, o, n_out);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
 }
 
 // ---- nullable predicate leaf: workspace + NOT-NULL root -------------------------------------

@@ -113,6 +113,40 @@ constexpr uint32_t deposit_lut_entry(uint32_t i) {
   return d;
 }
 
+// ---- extract (pext), the inverse of deposit: table[mask4 << 4 | src4] -------------------------
+constexpr uint32_t extract_lut_entry(uint32_t i) {
+  const uint32_t m = i >> 4, v = i & 15u;
+  uint32_t e = 0, j = 0;
+  for (uint32_t bit = 0; bit < 4; ++bit) {
+    if (m & (1u << bit)) {
+      if (v & (1u << bit)) e |= 1u << j;
+      ++j;
+    }
+  }
+  return e;
+}
+
+// the src bits at the set positions of mask, packed from bit 0 up
+__device__ __forceinline__ u64 extract64(u64 src, u64 mask, const uint8_t* __restrict__ lut) {
+  u64 out = 0;
+  uint32_t pos = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t mh = (uint32_t)(mask >> (32 * h)), sh = (uint32_t)(src >> (32 * h));
+    uint32_t o = 0, rank = 0;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const uint32_t m4 = (mh >> (4 * n)) & 15u;
+      const uint32_t s4 = (sh >> (4 * n)) & 15u;
+      o |= (uint32_t)lut[(m4 << 4) | s4] << rank;  // rank <= 28, the piece has <= 4 bits
+      rank += (uint32_t)__builtin_popcount(m4);
+    }
+    out |= (u64)o << pos;
+    pos += rank;
+  }
+  return out;
+}
+
 // tile_counts[t] = set root bits of tile t; tile_counts[tiles + 4 t + w] = those of its wave w (the
 // quarter tiles expand_kernel works on).  One workgroup of 256 threads per tile.
 // ZERO: also clears the words of 'zero_out' that belong to the tile (the compress output must start

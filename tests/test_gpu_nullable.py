@@ -223,3 +223,60 @@ def test_program_with_optional_columns(capi, O):
     # the leaf alone agrees with the stand-alone entry point
     solo = capi.eval_program([L(2, O.OP_LE, 4)], cols, n)
     assert torch.equal(solo, capi.fle_pred_nullable(dc, 2, 2, n, ec, len(c_vals), 3, O.OP_LE, 4))
+
+
+@pytest.mark.parametrize("bw", [1, 3, 7, 8, 12, 16, 21, 32])
+def test_select_nullable_against_row_model(capi, O, bw):
+    """ips_dict_select_nullable (ReadValue(skip) over a whole selection on an OPTIONAL column,
+    hdfs-parquet-scanner.cc:1006-1038): dense values of the selected NOT-NULL rows in row order,
+    one NOT-NULL flag per selected row, both counts -- against a numpy row model; raw FLE values and
+    dictionaries of 4- and 8-byte entries, ragged sizes, NULL stretches longer than a wave's 16 384
+    rows, selectivities from a handful of rows to all, data buffers shorter than the NOT-NULL count,
+    level widths 1 and 2."""
+    rng = np.random.default_rng(500 + bw)
+    for n, null_frac, sel_frac, max_def in ((1, 0.0, 1.0, 1), (65, 0.5, 0.5, 1), (4097, 0.1, 0.01, 1),
+                                            (200003, 0.3, 0.1, 1), (200003 + 64 * bw, 0.1, 1.0, 1),
+                                            (150001, 0.6, 0.3, 2), (70001, 1.0, 0.5, 1), (70001, 0.2, 0.0, 1)):
+        is_set = rng.random(n) >= null_frac
+        if n > 100000:
+            is_set[30000:50000] = False
+            is_set[60000:80000] = True
+        sel = rng.random(n) < sel_frac
+        if sel_frac >= 1.0:
+            sel[:] = True
+        k = int(is_set.sum())
+        def_bw = 1 if max_def == 1 else 2
+        levels = np.where(is_set, max_def, rng.integers(0, max_def, n)).astype(np.uint32)
+        d_defs = dev_words(O.fle_encode(levels, def_bw))
+        d_sel = dev_words(np.packbits(np.concatenate([sel, np.zeros((-n) % 64, bool)]), bitorder="little").view(np.uint64))
+        for kind in ("raw", "i32", "i64"):
+            if kind != "raw" and bw > 16:
+                continue
+            if kind == "raw":
+                dd, codes = None, rng.integers(0, 1 << bw, max(k, 1), dtype=np.uint64).astype(np.uint32)[:k]
+                values = codes.astype(np.int64)
+            else:
+                D = min(1 << bw, 3000)
+                npt = np.int32 if kind == "i32" else np.int64
+                entries = np.sort(rng.choice(np.arange(-10 ** 6, 10 ** 6), D, replace=False)).astype(npt)
+                dd = capi.Dict(entries.view(np.uint8), capi.T_INT32 if kind == "i32" else capi.T_INT64)
+                codes = rng.integers(0, D, max(k, 1)).astype(np.uint32)[:k]
+                values = entries[codes].astype(np.int64)
+            d_enc = dev_words(O.fle_encode(codes, bw)) if k else dev_words(np.zeros(2, np.uint64))
+            for n_data in sorted({k, ((k + 63) // 64) * 64, k // 2}):
+                usable = min(n_data, k)
+                rank = np.cumsum(is_set) - 1                       # data row of a NOT-NULL row
+                take = sel & is_set & (rank < usable)
+                exp_dense = values[rank[take]]
+                exp_flags = is_set[sel]
+                dense, flags, n_sel, n_val = capi.select_nullable(dd, d_defs, def_bw, max_def, n, d_enc, n_data, bw, d_sel)
+                ctx = (bw, n, null_frac, sel_frac, kind, n_data)
+                assert n_sel == int(sel.sum()), ctx
+                assert n_val == len(exp_dense), ctx
+                got = dense.cpu().numpy()
+                got = got.view(np.uint32).astype(np.int64) if kind == "raw" else got.astype(np.int64)
+                assert np.array_equal(got, exp_dense), ctx
+                got_flags = bits_of(words(flags), n_sel)
+                assert np.array_equal(got_flags, exp_flags), ctx
+            if dd is not None:
+                dd.close()
