@@ -866,6 +866,10 @@ struct SelNullWs {
   size_t total;
 };
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+bool select_nullable_one_pass() {  // dev switch for A/B runs: IPS_SELECT_NULLABLE_STEPS=1 composes the call from ten launches
+  static const bool on = getenv("IPS_SELECT_NULLABLE_STEPS") == nullptr;
+  return on;
+}
 SelNullWs sel_null_ws(void* base, int64_t n_rows, int64_t n_data_rows, int value_width) {
   const size_t bm = align256((size_t)((n_rows + 63) / 64) * 8);
   const int64_t nb = n_batches_of(n_data_rows > 0 ? n_data_rows : 1);
@@ -877,9 +881,15 @@ SelNullWs sel_null_ws(void* base, int64_t n_rows, int64_t n_data_rows, int value
   w.rank_rs = reinterpret_cast<uint32_t*>(p + off); off += rank_workspace_bytes(n_rows);
   w.nonnull = reinterpret_cast<uint64_t*>(p + off); off += bm;
   w.data_sel = reinterpret_cast<uint64_t*>(p + off); off += bm;
-  w.batch_values = p + off; off += align256((size_t)nb * IPS_BATCH_ROWS * (size_t)value_width);
-  w.batch_counts = reinterpret_cast<uint32_t*>(p + off); off += align256((size_t)nb * 4);
-  w.compact_ws = p + off; off += align256(batches_workspace_bytes(nb));
+  if (!select_nullable_one_pass()) {  // per-batch buffers of the step-by-step route only
+    w.batch_values = p + off; off += align256((size_t)nb * IPS_BATCH_ROWS * (size_t)value_width);
+    w.batch_counts = reinterpret_cast<uint32_t*>(p + off); off += align256((size_t)nb * 4);
+    w.compact_ws = p + off; off += align256(batches_workspace_bytes(nb));
+  } else {
+    w.batch_values = nullptr;
+    w.batch_counts = nullptr;
+    w.compact_ws = nullptr;
+  }
   w.total = off;
   return w;
 }
@@ -916,7 +926,7 @@ ips_status ips_dict_select_nullable(const ips_dict* dict, const void* d_def_leve
   nws.nonnull = w.nonnull;
   int root_kind = 0;
   const uint64_t* root = nullptr;
-  static const bool one_pass = getenv("IPS_SELECT_NULLABLE_STEPS") == nullptr;  // dev switch for A/B runs
+  const bool one_pass = select_nullable_one_pass();
   st = nullable_prepare_root(d_def_levels, def_bit_width, max_def_level, n_rows, nws, &root_kind, &root, s,
                              /*count_tiles=*/false);
   if (st != IPS_OK) return st;
