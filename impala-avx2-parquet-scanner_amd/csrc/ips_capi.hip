@@ -932,9 +932,8 @@ ips_status ips_dict_select_nullable(const ips_dict* dict, const void* d_def_leve
   if (st != IPS_OK) return st;
   if (one_pass) {
     // counts of NOT-NULL / selected / selected NOT-NULL rows per rank tile (and the flag words
-    // cleared), then values: fle_select_nullable_kernel, then the NOT-NULL flag of every selected
-    // row (the NULL indicator bit, hdfs-parquet-scanner.cc:1022-1026) by the compress kernel on the
-    // selection's counts
+    // cleared), then fle_select_nullable_kernel: values, the NOT-NULL flag of every selected row
+    // (the NULL indicator bit, hdfs-parquet-scanner.cc:1022-1026) and both counts
     st = launch_rank3_counts(root_kind, root, d_selection, n_rows, w.rank, w.rank_s, w.rank_rs, d_nonnull_flags, s);
     if (st != IPS_OK) return st;
     const int64_t n_data = n_data_rows < n_rows ? n_data_rows : n_rows;
@@ -943,16 +942,18 @@ ips_status ips_dict_select_nullable(const ips_dict* dict, const void* d_def_leve
       a.root = reinterpret_cast<const unsigned long long*>(root);
       a.sel = reinterpret_cast<const unsigned long long*>(d_selection);
       a.c_r = w.rank;
+      a.c_s = w.rank_s;
       a.c_rs = w.rank_rs;
+      a.flags = reinterpret_cast<unsigned long long*>(d_nonnull_flags);
+      a.n_selected = d_counts;
       a.n_rows = n_rows;
       a.root_kind = root_kind;
       st = launch_fle_selnull(bit_width, dict ? dict->slot : 0, reinterpret_cast<const uint64_t*>(d_codes_enc), n_data,
                               a, d_dense_values, dict ? dict->d_entries : nullptr, dict ? (uint32_t)dict->n : 0u,
                               d_counts + 1, s);
-      if (st != IPS_OK) return st;
-    } else {
-      IPS_HIP_TRY(hipMemsetAsync(d_counts + 1, 0, 8, s));
+      return st;  // (the kernel also wrote the flags and the number of selected rows)
     }
+    IPS_HIP_TRY(hipMemsetAsync(d_counts + 1, 0, 8, s));
     return launch_compress_counted(0, d_selection, root_kind, root, n_rows, d_nonnull_flags, d_counts, w.rank_s, s);
   }
   // 1. the selection over the DATA rows (the rows ReadValue decodes once ReadDefinitionLevel said

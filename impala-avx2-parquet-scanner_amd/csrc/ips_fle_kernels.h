@@ -834,7 +834,10 @@ struct SelNullArgs {
   const unsigned long long* root;
   const unsigned long long* sel;
   const uint32_t* c_r;
+  const uint32_t* c_s;
   const uint32_t* c_rs;
+  unsigned long long* flags;  // one NOT-NULL bit per selected row, cleared by the counting pass
+  int64_t* n_selected;        // popcount of the selection
   int64_t n_rows;
   int32_t root_kind;
 };
@@ -852,8 +855,8 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_select_nul
   __shared__ __attribute__((aligned(16))) u64 seg_all[kWavesPerBlock][kSegWords64];
   __shared__ uint16_t list_all[kWavesPerBlock][kListMax];
   __shared__ uint8_t lut[256];
-  __shared__ u64 part_r[kRankWaves], part_rs[kRankWaves];
-  __shared__ uint32_t tot_r[kRankWaves], tot_rs[kRankWaves];
+  __shared__ u64 part_r[kRankWaves], part_s[kRankWaves], part_rs[kRankWaves];
+  __shared__ uint32_t tot_r[kRankWaves], tot_s[kRankWaves], tot_rs[kRankWaves];
   constexpr int L = (16 * W + kWave - 1) / kWave;
   const int lane = lane_id();
   const int wave = wave_id();
@@ -874,47 +877,97 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_select_nul
   else load_root<kRootBitmap, kExpRounds>(root, first, n_words, n_rows, lane, m);
   load_root<kRootBitmap, kExpRounds>(sel, first, n_words, n_rows, lane, sv);
 
-  // ranks of the workgroup's first word in R and RS (see expand_kernel)
+  // ranks of the workgroup's first word in R, S and RS (see expand_kernel)
   const int64_t tile = (int64_t)blockIdx.x / kExpBlocksPerTile;
   const int part_waves = (int)(blockIdx.x % kExpBlocksPerTile) * (kRankWaves / kExpBlocksPerTile);
-  uint32_t before_r = 0, before_rs = 0;
+  uint32_t before_r = 0, before_s = 0, before_rs = 0;
   for (int64_t i = threadIdx.x; i < tile; i += kRankThreads) {
     before_r += a.c_r[i];
+    before_s += a.c_s[i];
     before_rs += a.c_rs[i];
   }
   if ((int)threadIdx.x < part_waves) {
     before_r += a.c_r[tiles + tile * kRankWaves + threadIdx.x];
+    before_s += a.c_s[tiles + tile * kRankWaves + threadIdx.x];
     before_rs += a.c_rs[tiles + tile * kRankWaves + threadIdx.x];
   }
   {
     const uint32_t lo = wave_sum(before_r & 0xFFFFu), hi = wave_sum(before_r >> 16);
+    const uint32_t lo1 = wave_sum(before_s & 0xFFFFu), hi1 = wave_sum(before_s >> 16);
     const uint32_t lo2 = wave_sum(before_rs & 0xFFFFu), hi2 = wave_sum(before_rs >> 16);
     if (lane == 0) {
       part_r[wave] = (u64)lo + ((u64)hi << 16);
+      part_s[wave] = (u64)lo1 + ((u64)hi1 << 16);
       part_rs[wave] = (u64)lo2 + ((u64)hi2 << 16);
     }
   }
-  uint32_t excl[kExpRounds];
-  uint32_t run_r = 0, mine_rs = 0;
+  uint32_t excl[kExpRounds], excl_s[kExpRounds];
+  uint32_t run_r = 0, run_s = 0, mine_rs = 0;
 #pragma unroll
   for (int r = 0; r < kExpRounds; ++r) {
     const uint32_t c = (uint32_t)(__builtin_popcountll(m[r][0]) + __builtin_popcountll(m[r][1]));
     const uint32_t incl = wave_inclusive_scan(c);
     excl[r] = run_r + incl - c;
     run_r += __builtin_amdgcn_readlane(incl, 63);
+    const uint32_t cs = (uint32_t)(__builtin_popcountll(sv[r][0]) + __builtin_popcountll(sv[r][1]));
+    const uint32_t incl_s = wave_inclusive_scan(cs);
+    excl_s[r] = run_s + incl_s - cs;
+    run_s += __builtin_amdgcn_readlane(incl_s, 63);
     mine_rs += (uint32_t)(__builtin_popcountll(m[r][0] & sv[r][0]) + __builtin_popcountll(m[r][1] & sv[r][1]));
   }
   const uint32_t run_rs = wave_sum(mine_rs);
   if (lane == 0) {
     tot_r[wave] = run_r;
+    tot_s[wave] = run_s;
     tot_rs[wave] = run_rs;
   }
   __syncthreads();
   u64 base_r = part_r[0] + part_r[1] + part_r[2] + part_r[3];
+  u64 base_s = part_s[0] + part_s[1] + part_s[2] + part_s[3];
   u64 base_rs = part_rs[0] + part_rs[1] + part_rs[2] + part_rs[3];
   for (int w = 0; w < wave; ++w) {
     base_r += tot_r[w];
+    base_s += tot_s[w];
     base_rs += tot_rs[w];
+  }
+  if (a.n_selected && blockIdx.x == gridDim.x - 1 && threadIdx.x == kRankThreads - 1)
+    *a.n_selected = (int64_t)(base_s + run_s);  // last wave of the last block: popcount(selection)
+
+  // the NOT-NULL flag of every selected row (the NULL indicator bit, hdfs-parquet-scanner.cc:
+  // 1022-1026): the NOT-NULL bits at the selected positions, appended at the wave's rank in S.
+  // As in compress_kernel the wave assembles its bits in the LDS segment; the two end words can be
+  // shared with the neighbouring waves and leave as atomics (the counting pass cleared the words).
+  {
+    const uint32_t lead_s = (uint32_t)(base_s & 63);
+#pragma unroll
+    for (int r = 0; r < kExpRounds; ++r) {
+      uint32_t o = lead_s + excl_s[r];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const u64 sk = sv[r][e];
+        if ((sk & m[r][e]) != 0ull) {
+          const u64 bits = extract64(m[r][e], sk, lut);
+          const uint32_t sh = o & 63u;
+          __hip_atomic_fetch_or(&seg[o >> 6], bits << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (sh && (bits >> (64 - sh)))
+            __hip_atomic_fetch_or(&seg[(o >> 6) + 1], bits >> (64 - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        o += (uint32_t)__builtin_popcountll(sk);
+      }
+    }
+    wave_lds_fence();
+    const int64_t g0 = (int64_t)(base_s >> 6);
+    const uint32_t nw = run_s ? (lead_s + run_s + 63) / 64 : 0;
+    for (uint32_t i = lane; i < nw; i += kWave) {
+      const u64 v = seg[i];
+      if (i == 0 || i == nw - 1) {
+        if (v) atomicOr(a.flags + g0 + i, (unsigned long long)v);
+      } else {
+        a.flags[g0 + i] = v;
+      }
+      seg[i] = 0ull;  // the segment is used again below
+    }
+    wave_lds_fence();
   }
 
   // the selection over the wave's data rows: bit (lead + rank inside the wave) of the segment
