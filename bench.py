@@ -185,8 +185,34 @@ def leg_nullable(capi, dev, n):
     sel_rows[is_set] = vals < 409
     ok = capi.bitmap_count(bm, n) == int(sel_rows.sum().item())
     byts = (n + 63) // 64 * 8 * 2 + n_data // 64 * 12 * 8
-    return [rec("OPTIONAL FLE w=12 column, 10% NULL, LT @10%: nullable leaf (levels + data -> bitmap)", n, byts,
-                tmed, tmin, bool(ok), non_null_rows=k)]
+    out = [rec("OPTIONAL FLE w=12 column, 10% NULL, LT @10%: nullable leaf (levels + data -> bitmap)", n, byts,
+               tmed, tmin, bool(ok), non_null_rows=k)]
+    # late materialisation of the same column for the rows the leaf selected (ReadValue(skip) over the
+    # whole selection): dense values of the selected rows + one NOT-NULL flag per selected row
+    import ctypes as C
+    lib = capi.lib()
+    lib.ips_select_nullable_workspace_bytes.restype = C.c_size_t
+    ws2 = torch.empty(int(lib.ips_select_nullable_workspace_bytes(C.c_int64(n), C.c_int64(n_data), 4)) + 16,
+                      dtype=torch.uint8, device=dev)
+    n_sel = int(sel_rows.sum().item())
+    dense = torch.empty(n_sel + 64, dtype=torch.int32, device=dev)
+    flags = torch.empty((n + 63) // 64, dtype=torch.int64, device=dev)
+    cnts = torch.zeros(2, dtype=torch.int64, device=dev)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    stream = capi._stream(None)
+
+    def mat():
+        capi._ck(lib.ips_dict_select_nullable(None, P(defs), 1, 1, C.c_int64(n), P(enc), C.c_int64(n_data), 12,
+                                              P(bm), P(dense), P(flags), P(cnts), P(ws2), stream))
+    tmed, tmin = time_launches(mat)
+    got = cnts.cpu().tolist()
+    ok2 = (got == [n_sel, n_sel] and torch.equal(dense[:n_sel], vals[vals < 409].to(torch.int32))
+           and capi.bitmap_count(flags, n_sel) == n_sel)
+    byts2 = (n + 63) // 64 * 8 * 2 + n_data // 64 * 12 * 8 + 4 * n_sel + n_sel // 8
+    out.append(rec("OPTIONAL FLE w=12 column, 10% NULL: late materialisation of the leaf's selection "
+                   "(levels + selection + data -> dense values + NOT-NULL flags, 2 launches)", n, byts2, tmed, tmin,
+                   bool(ok2), selected_rows=n_sel))
+    return out
 
 
 def q6_piece(ips, capi, dev, row0, rows):
