@@ -52,8 +52,14 @@ __global__ __launch_bounds__(256) void bitmap_count_kernel(const uint64_t* __res
   const int64_t n_pairs = n_words / 2;  // 16-byte loads; the last (maybe partial) words go scalar
   unsigned long long c = 0;
   const ulonglong2* a2 = reinterpret_cast<const ulonglong2*>(a);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs;
-       i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; 2 * (i + 3 * step) + 2 < n_words; i += 4 * step) {  // four loads in flight, all words full
+    const ulonglong2 w0 = a2[i], w1 = a2[i + step], w2 = a2[i + 2 * step], w3 = a2[i + 3 * step];
+    c += __builtin_popcountll(w0.x) + __builtin_popcountll(w0.y) + __builtin_popcountll(w1.x) + __builtin_popcountll(w1.y) +
+         __builtin_popcountll(w2.x) + __builtin_popcountll(w2.y) + __builtin_popcountll(w3.x) + __builtin_popcountll(w3.y);
+  }
+  for (; i < n_pairs; i += step) {
     if (2 * i + 2 < n_words) {  // both words are full
       ulonglong2 w = a2[i];
       c += __builtin_popcountll(w.x) + __builtin_popcountll(w.y);
@@ -107,7 +113,7 @@ ips_status launch_bitmap_count(const uint64_t* a, int64_t n_rows, int64_t* count
   IPS_HIP_TRY(hipMemsetAsync(count, 0, 8, s));
   if (n_rows <= 0) return IPS_OK;
   int grid = small_grid((n_rows + 127) / 128, 256);
-  if (grid > device_cus() * 2) grid = device_cus() * 2;  // one atomic per block
+  if (grid > device_cus() * 4) grid = device_cus() * 4;  // one atomic per block
   hipLaunchKernelGGL(bitmap_count_kernel, dim3(grid), dim3(256), 0, s, a, n_rows,
                      reinterpret_cast<unsigned long long*>(count));
   IPS_HIP_TRY(hipGetLastError());
