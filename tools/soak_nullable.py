@@ -78,6 +78,36 @@ for it in range(int(os.environ.get("IPS_SOAK_ITERS", "250"))):
         bad += 1
         print("leaf mismatch", dict(bw=bw, n=n, max_def=max_def, k=k, n_data=n_data, op=op), flush=True)
         continue
+    # late materialisation of the rows the leaf selected, or of a random selection
+    if rng.random() < 0.5:
+        selbits = bits_of(exp, n)
+        d_sel = out[:(n + 63) // 64 + 1]
+    else:
+        selbits = rng.random(n) < rng.random()
+        d_sel = dev(np.packbits(np.concatenate([selbits, np.zeros((-n) % 64, bool)]), bitorder="little").view(np.uint64))
+    if bw <= 16 and rng.random() < 0.5:
+        D = 1 << bw
+        entries = (np.arange(D, dtype=np.int64) * 7 - 1000)
+        if rng.random() < 0.5:
+            dd, ent = capi.Dict(entries.astype(np.int32).view(np.uint8), capi.T_INT32), entries.astype(np.int32).astype(np.int64)
+        else:
+            entries = entries * (1 << 33)
+            dd, ent = capi.Dict(entries.view(np.uint8), capi.T_INT64), entries
+        values = ent[vals] if k else np.zeros(0, np.int64)
+    else:
+        dd, values = None, vals.astype(np.int64)
+    rank = np.cumsum(is_set) - 1
+    take = selbits & is_set & (rank < min(n_data, k))
+    exp_dense = values[rank[take]]
+    dense, flags, n_sel, n_val = capi.select_nullable(dd, d_defs, def_bw, max_def, n, d_enc, n_data, bw, d_sel)
+    got = dense.cpu().numpy()
+    got = got.view(np.uint32).astype(np.int64) if dd is None else got.astype(np.int64)
+    if (n_sel != int(selbits.sum()) or n_val != len(exp_dense) or not np.array_equal(got, exp_dense)
+            or not np.array_equal(bits_of(words(flags), n_sel), is_set[selbits])):
+        bad += 1
+        print("select_nullable mismatch", dict(bw=bw, n=n, max_def=max_def, k=k, n_data=n_data, dict=dd is not None), flush=True)
+    if dd is not None:
+        dd.close()
     if op != 5 and n_data == k:
         # the same leaf and-ed / or-ed into a REQUIRED column's predicate through the program
         other = rng.integers(0, 8, n).astype(np.uint32)
