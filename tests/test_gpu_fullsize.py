@@ -147,6 +147,39 @@ def test_more_than_2_31_rows(capi, ips):
     assert torch.equal(bits.bool(), (vals[lo:lo + 128] >= 2).cpu())
 
 
+def test_optional_column_beyond_2_31_rows(capi, ips):
+    """An OPTIONAL column of 2^31 + 70 001 rows (half of them NULL, w = 3): the one-pass nullable
+    leaf and the late materialisation of its selection -- ranks, data-row indices and dense
+    output positions beyond 32 bits -- against torch on the raw values."""
+    n, bw = (1 << 31) + 70001, 3
+    is_set = (capi.synth_u32(0x5EED0E1, n, 1) == 1)
+    defs = capi.fle_encode(is_set.to(torch.int32), 1)
+    k = int(is_set.sum().item())
+    vals = capi.synth_u32(0x5EED0E2, k, bw)
+    enc = capi.fle_encode(vals, bw)
+    bm = capi.fle_pred_nullable(defs, 1, 1, n, enc, k, bw, capi.OP_LT, 2)
+    truth = torch.zeros(n, dtype=torch.bool, device="cuda")
+    pos = 0
+    for c0 in range(0, n, 1 << 30):    # (boolean-mask assignment in pieces torch can index)
+        piece = is_set[c0:c0 + (1 << 30)]
+        cnt = int(piece.sum().item())
+        truth[c0:c0 + (1 << 30)][piece] = vals[pos:pos + cnt] < 2
+        pos += cnt
+    n_true = int(truth.sum().item())
+    assert capi.bitmap_count(bm, n) == n_true
+    for lo in ((1 << 31) - 128, ((n - 300) // 64) * 64):   # both sides of 2^31, and the ragged end
+        hi = min(lo + 256, n)
+        words = bm[lo // 64:(hi + 63) // 64].cpu().tolist()
+        bits = torch.tensor([(words[(lo + i) // 64 - lo // 64] >> ((lo + i) % 64)) & 1 for i in range(hi - lo)])
+        assert torch.equal(bits.bool(), truth[lo:hi].cpu())
+    assert (int(bm[-1].item()) & 0xFFFFFFFFFFFFFFFF) >> (n % 64) == 0
+    del truth
+    dense, flags, n_sel, n_val = capi.select_nullable(None, defs, 1, 1, n, enc, k, bw, bm)
+    assert n_sel == n_val == n_true                      # every selected row is NOT NULL
+    assert torch.equal(dense, vals[vals < 2])
+    assert capi.bitmap_count(flags, n_sel) == n_sel
+
+
 def _pack(mask):
     w = mask.view(-1, 64).to(torch.int64)
     return (w << torch.arange(64, device=w.device, dtype=torch.int64)).sum(dim=1)
