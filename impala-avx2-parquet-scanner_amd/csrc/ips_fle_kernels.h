@@ -669,6 +669,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_w_ker
 // nine sub-tiles -- into a bitmap segment in LDS, and deposits that segment into the NOT-NULL
 // positions.  The data-row bitmap never exists in HBM (the three-launch route writes and re-reads
 // it: 60 MB of 520 on a 2^28-row column) and the levels are read twice instead of three times.
+// Long IN lists on codes of <= 16 bits go through the 2^w-bit membership table, built per workgroup.
 // args.aux_root / aux_kind / aux_rows / aux_counts: the NOT-NULL root, its kind, the row count
 // and the tile counts (complete before this launch); args.combine: 0 store, 1 and, 2 or into out.
 // ---------------------------------------------------------------------------------------------
@@ -679,9 +680,12 @@ static_assert(kThreads == kRankThreads, "a leaf workgroup is an expand workgroup
 template <int W, int KIND>
 __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_leaf_kernel(
     const uint64_t* __restrict__ enc, int64_t n_sub, PredArgs args, u64* __restrict__ out) {
-  static_assert(KIND != kPredInTable, "long IN lists take the three-launch route");
+  constexpr bool kInTable = KIND == kPredInTable && InTable<W>::kUse;
+  static_assert(KIND != kPredInTable || InTable<W>::kUse, "the membership table holds codes of <= 16 bits");
   __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * plane_tile_bytes(W) / 4];
   __shared__ uint32_t seg_all[kWavesPerBlock][kLeafSegDwords];
+  __shared__ uint32_t in_table[kInTable ? InTable<W>::kDwords : 1];
+  if constexpr (kInTable) in_table_build<W>(in_table, args);
   __shared__ uint8_t lut[256];
   __shared__ u64 part[kRankWaves];
   __shared__ uint32_t wave_tot[kRankWaves];
@@ -764,6 +768,12 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_leaf_kerne
       uint32_t r1, r2;
       pred_pair_from_lds(lds32, W, lane, args.op, args.consts[0], args.op2, args.const2, &r1, &r2);
       sel = args.join == 1 ? (r1 & r2) : (r1 | r2);
+    } else if (kInTable) {  // long list: decode, one set lookup per value
+      uint32_t p[W];
+      planes_from_lds<W>(lds32, lane, p);
+      uint32_t v[32];
+      planes_to_values<W>(p, v);
+      sel = bitrev32(in_table_lookup(in_table, v));
     } else if (W <= 16) {
       uint32_t p[W];
       planes_from_lds<W>(lds32, lane, p);

@@ -164,7 +164,7 @@ static ips_status launch_pred_w(const uint64_t* enc, int64_t n_rows, const PredA
 
 // The fused nullable leaf (fle_leaf_kernel): one workgroup per quarter rank tile of output words.
 // *taken = false (nothing launched) for the shapes that keep predicate and expand as separate
-// launches: IN lists long enough for the membership table, comparisons at w = 32.
+// launches: comparisons at w = 32 (the early-pruning predicate reads half the planes).
 template <int W>
 static ips_status launch_leaf_w(const uint64_t* enc, int64_t n_sub, const PredArgs& args, uint64_t* out,
                                 bool* taken, hipStream_t s) {
@@ -186,7 +186,8 @@ static ips_status launch_leaf_w(const uint64_t* enc, int64_t n_sub, const PredAr
   } else if (args.op == 5) {
     if constexpr (W <= 16) {
       if (args.n_consts >= in_table_min_pred(W)) {
-        *taken = false;
+        hipLaunchKernelGGL((fle_leaf_kernel<W, kPredInTable>), grid, dim3(kThreads), 0, s, enc, n_sub, args, o);
+        IPS_HIP_TRY(hipGetLastError());
         return IPS_OK;
       }
     }

@@ -43,7 +43,8 @@ def main():
             alg = n / 8 * 2 + k * bw / 8
             t1 = med_us(lambda: capi.fle_pred_nullable(defs, 1, 1, n, enc, n_data, bw, capi.OP_LT, c, bitmap=bm, workspace=ws))
             t2 = med_us(lambda: capi.fle_pred_nullable(defs, 1, 1, n, enc, n_data, bw, capi.OP_IN, [1, 2, 3, c], bitmap=bm, workspace=ws))
-            print(f"null {null_frac:.1f} w={bw:2d}: LT {t1:7.1f} us ({alg / t1 / 8e6 * 100:4.1f} %)   IN4 {t2:7.1f} us", flush=True)
+            t3 = med_us(lambda: capi.fle_pred_nullable(defs, 1, 1, n, enc, n_data, bw, capi.OP_IN, [(c + 7 * i) % (1 << bw) for i in range(40)], bitmap=bm, workspace=ws)) if bw <= 16 else 0.0
+            print(f"null {null_frac:.1f} w={bw:2d}: LT {t1:7.1f} us ({alg / t1 / 8e6 * 100:4.1f} %)   IN4 {t2:7.1f} us   IN40 {t3:7.1f} us", flush=True)
             del enc
 
 
