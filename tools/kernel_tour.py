@@ -148,7 +148,19 @@ n_data = ((k + 63) // 64) * 64
 wsn = capi.nullable_workspace(n, dev)
 run("nullable leaf w=12, 10% NULL (counts + leaf)", "fle_leaf_kernel<12, 0>", W * 16 + n_data // 64 * 96,
     lambda: capi.fle_pred_nullable(defs, 1, 1, n, venc, n_data, 12, capi.OP_LT, 409, bitmap=bm, workspace=wsn))
-del defs, venc, wsn
+# late materialisation of the rows the leaf selected (raw values): counts + select kernel
+lib.ips_select_nullable_workspace_bytes.restype = C.c_size_t
+ws_sn = torch.empty(int(lib.ips_select_nullable_workspace_bytes(N, C.c_int64(n_data), 4)) + 16, dtype=torch.uint8, device=dev)
+sel_bm = bm.clone()
+n_sel_nn = capi.bitmap_count(sel_bm, n)
+dense_sn = torch.empty(n_sel_nn + 64, dtype=torch.int32, device=dev)
+flags_sn = torch.empty(W, dtype=torch.int64, device=dev)
+cnt_sn = torch.zeros(2, dtype=torch.int64, device=dev)
+run("select_nullable w=12, 10% NULL, the leaf's selection (counts + select)", "fle_select_nullable_kernel<12, 0>",
+    W * 16 + n_data // 64 * 96 + 4 * n_sel_nn + n_sel_nn // 8,
+    lambda: capi._ck(lib.ips_dict_select_nullable(None, P(defs), 1, 1, N, P(venc), C.c_int64(n_data), 12, P(sel_bm), P(dense_sn),
+                                                  P(flags_sn), P(cnt_sn), P(ws_sn), S)))
+del defs, venc, wsn, ws_sn, dense_sn, flags_sn, sel_bm
 
 # Q6 program
 q6 = ips.q6
