@@ -831,11 +831,13 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_leaf_kerne
 // hdfs-parquet-scanner.cc:1006-1038 + 927-979: ReadDefinitionLevel says which selected rows are
 // NULL and which data row a NOT-NULL one decodes).  A workgroup owns a quarter rank tile of ROWS
 // (1024 words; a wave 256 words = 16 384 rows).  From the three count tables of
-// rank3_counts_kernel the wave knows the data row of its first NOT-NULL row (R) and the dense
-// output index of its first selected NOT-NULL row (RS).  It extracts the selection at the
-// NOT-NULL positions (pext through the nibble table) into an LDS segment -- the selection over
-// its OWN data rows, which the three-launch route wrote to HBM as a bitmap over all data rows --
-// then walks the data sub-tiles that hold them: blocks without a selected row are not loaded,
+// rank3_counts_kernel the wave knows the data row of its first NOT-NULL row (R), the index of its
+// first selected row (S) and the dense output index of its first selected NOT-NULL row (RS).
+// First the NOT-NULL flag of every selected row: the NOT-NULL bits at the selected positions
+// (pext through the nibble table), assembled in an LDS segment and flushed at the wave's S-rank.
+// Then it extracts the selection at the NOT-NULL positions into the same segment -- the selection
+// over its OWN data rows, which the step-by-step route wrote to HBM as a bitmap over all data rows
+// -- and walks the data sub-tiles that hold them: blocks without a selected row are not loaded,
 // of the others the selected rows go on an index list and are decoded one per lane straight from
 // the plane image (through the dictionary if there is one) into dense[RS index .. ), coalesced and
 // in row order.  No per-batch buffers, no compaction pass.
