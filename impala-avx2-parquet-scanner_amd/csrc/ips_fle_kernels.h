@@ -753,39 +753,131 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_leaf_kerne
 #pragma unroll
     for (int i = 0; i < L; ++i) r[i] = buffer_load16<true>(rsrc, (uint32_t)(i * kWave + lane) * 16u);
   };
-  u32x4 r[L];
-  if (n_st > 0) load(0, r);
-  for (int k = 0; k < n_st; ++k) {
-    tile_to_lds<L>(lds32, W, lane, r);
-    if (k + 1 < n_st) load(k + 1, r);  // register prefetch
-    wave_lds_fence();
-    uint32_t sel;
-    if (KIND == kPredSingle) {
-      uint32_t p[W];
-      planes_from_lds<W>(lds32, lane, p);
-      sel = pred_from_regs<W>(p, args);
-    } else if (KIND == kPredPair) {
-      uint32_t r1, r2;
-      pred_pair_from_lds(lds32, W, lane, args.op, args.consts[0], args.op2, args.const2, &r1, &r2);
-      sel = args.join == 1 ? (r1 & r2) : (r1 | r2);
-    } else if (kInTable) {  // long list: decode, one set lookup per value
-      uint32_t p[W];
-      planes_from_lds<W>(lds32, lane, p);
-      uint32_t v[32];
-      planes_to_values<W>(p, v);
-      sel = bitrev32(in_table_lookup(in_table, v));
-    } else if (W <= 16) {
-      uint32_t p[W];
-      planes_from_lds<W>(lds32, lane, p);
-      sel = pred_in_from_regs<W>(p, args.consts, args.n_consts);
-    } else {
-      sel = pred_in_from_lds(lds32, W, lane, args.consts, args.n_consts);
+  constexpr bool kEarly = W == 32 && (KIND == kPredSingle || KIND == kPredPair);
+  if constexpr (kEarly) {
+    // w = 32 comparisons, early pruning as in fle_pred32_early_kernel: the high 16 planes of a
+    // sub-tile are loaded and evaluated first; the low 16 only if a row is still equal to a
+    // constant after them (and then prefetched while that keeps happening)
+    auto rsrc_of = [&](int k) {
+      const int64_t w0 = (b0 + (int64_t)k * kBlocksPerTile) * W;
+      int64_t left = total_words - w0;
+      const int64_t need = (int64_t)(n_blk - k * kBlocksPerTile) * W;
+      left = left < need ? left : need;
+      left = left < 0 ? 0 : (left > kBlocksPerTile * W ? kBlocksPerTile * W : left);
+      const uint64_t* bp = left > 0 ? enc + w0 : enc;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(bp), 0, (int)(left * 8), kBufferRsrcDword3);
+    };
+    // half = 1: words 16..31 of every block (planes 31..16), half = 0: words 0..15
+    auto load_half = [&](int k, int half, u32x4 (&r)[4]) {
+      const __amdgpu_buffer_rsrc_t rsrc = rsrc_of(k);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ch = i * kWave + lane;  // 256 chunks of 16 bytes per half sub-tile
+        r[i] = buffer_load16<true>(rsrc, (uint32_t)(((ch >> 3) * W + half * 16 + (ch & 7) * 2) * 8));
+      }
+    };
+    auto stage_half = [&](int half, const u32x4 (&r)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ch = i * kWave + lane;
+        uint32_t* dst = lds32 + 2 * ((ch >> 3) * plane_stride_words(W) + half * 16 + (ch & 7) * 2);
+        dst[0] = r[i].x; dst[1] = r[i].y; dst[2] = r[i].z; dst[3] = r[i].w;
+      }
+    };
+    struct Half { uint32_t b, eq; };
+    auto planes_step = [&](int half, uint32_t cc, uint32_t b_in) -> Half {
+      const uint32_t* p = lds32 + plane_base_dw(W, lane);
+      uint32_t x[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) x[e] = p[2 * (half * 16 + e)];
+      Half h{b_in, ~0u};
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        h.b = borrow_step(h.b, x[e], bit_mask(cc, half * 16 + e));
+        h.eq = eq_step(h.eq, x[e], bit_mask(cc, half * 16 + e));
+      }
+      return h;
+    };
+    auto finish = [&](int op, const Half& hi, bool with_lo, const Half& lo) -> uint32_t {
+      if (op == 0) return with_lo ? (hi.eq & lo.eq) : 0u;  // without the low half no row was still equal
+      const uint32_t b = with_lo ? (hi.b | (hi.eq & lo.b)) : hi.b;
+      return borrow_select(b, op);
+    };
+    const uint32_t c1 = args.consts[0], c2 = args.const2;
+    bool with_low = false;  // wave-uniform: the previous sub-tile needed the low planes
+    u32x4 rh[4], rl[4];
+    if (n_st > 0) load_half(0, 1, rh);
+    for (int k = 0; k < n_st; ++k) {
+      stage_half(1, rh);
+      const bool have_low = with_low;
+      if (have_low) stage_half(0, rl);
+      wave_lds_fence();
+      const Half hi = planes_step(1, c1, 0u);
+      Half hi2{0u, 0u}, lo{0u, 0u}, lo2{0u, 0u};
+      if (KIND == kPredPair) hi2 = planes_step(1, c2, 0u);
+      // data rows that do not exist are padding: never let them ask for the low planes
+      const int64_t valid = n_sub - ((b0 + (int64_t)k * kBlocksPerTile) * 64 + (int64_t)lane * 32);
+      const uint32_t live = valid >= 32 ? ~0u : valid <= 0 ? 0u : ~((1u << (32 - valid)) - 1u);  // MSB-first rows
+      const uint32_t open_rows = (KIND == kPredPair ? (hi.eq | hi2.eq) : hi.eq) & live;
+      const bool undecided = __builtin_amdgcn_ballot_w64(open_rows != 0u) != 0ull;
+      if (k + 1 < n_st) {  // prefetch: the high half always, the low half while the column needs it
+        load_half(k + 1, 1, rh);
+        if (undecided) load_half(k + 1, 0, rl);
+      }
+      if (undecided) {
+        if (!have_low) {  // demand fetch of this sub-tile's low lines
+          u32x4 now[4];
+          load_half(k, 0, now);
+          stage_half(0, now);
+          wave_lds_fence();
+        }
+        lo = planes_step(0, c1, borrow_init(args.op));
+        if (KIND == kPredPair) lo2 = planes_step(0, c2, borrow_init(args.op2));
+      }
+      with_low = undecided;
+      uint32_t sel = finish(args.op, hi, undecided, lo);
+      if (KIND == kPredPair) {
+        const uint32_t sel2 = finish(args.op2, hi2, undecided, lo2);
+        sel = args.join == 1 ? (sel & sel2) : (sel | sel2);
+      }
+      seg[k * 64 + lane] = bitrev32(sel & live);
+      wave_lds_fence();  // the plane image is reused by the next sub-tile; the segment is read below
     }
-    uint32_t bm = bitrev32(sel);
-    const int64_t valid = n_sub - ((b0 + (int64_t)k * kBlocksPerTile) * 64 + (int64_t)lane * 32);
-    if (valid < 32) bm = valid <= 0 ? 0u : (bm & ((1u << valid) - 1u));  // data rows that do not exist select nothing
-    seg[k * 64 + lane] = bm;
-    wave_lds_fence();  // the plane image is reused by the next sub-tile; the segment is read below
+  } else {
+    u32x4 r[L];
+    if (n_st > 0) load(0, r);
+    for (int k = 0; k < n_st; ++k) {
+      tile_to_lds<L>(lds32, W, lane, r);
+      if (k + 1 < n_st) load(k + 1, r);  // register prefetch
+      wave_lds_fence();
+      uint32_t sel;
+      if (KIND == kPredSingle) {
+        uint32_t p[W];
+        planes_from_lds<W>(lds32, lane, p);
+        sel = pred_from_regs<W>(p, args);
+      } else if (KIND == kPredPair) {
+        uint32_t r1, r2;
+        pred_pair_from_lds(lds32, W, lane, args.op, args.consts[0], args.op2, args.const2, &r1, &r2);
+        sel = args.join == 1 ? (r1 & r2) : (r1 | r2);
+      } else if (kInTable) {  // long list: decode, one set lookup per value
+        uint32_t p[W];
+        planes_from_lds<W>(lds32, lane, p);
+        uint32_t v[32];
+        planes_to_values<W>(p, v);
+        sel = bitrev32(in_table_lookup(in_table, v));
+      } else if (W <= 16) {
+        uint32_t p[W];
+        planes_from_lds<W>(lds32, lane, p);
+        sel = pred_in_from_regs<W>(p, args.consts, args.n_consts);
+      } else {
+        sel = pred_in_from_lds(lds32, W, lane, args.consts, args.n_consts);
+      }
+      uint32_t bm = bitrev32(sel);
+      const int64_t valid = n_sub - ((b0 + (int64_t)k * kBlocksPerTile) * 64 + (int64_t)lane * 32);
+      if (valid < 32) bm = valid <= 0 ? 0u : (bm & ((1u << valid) - 1u));  // data rows that do not exist select nothing
+      seg[k * 64 + lane] = bm;
+      wave_lds_fence();  // the plane image is reused by the next sub-tile; the segment is read below
+    }
   }
 
   // deposit: the window of a word = three segment dwords from its rank on

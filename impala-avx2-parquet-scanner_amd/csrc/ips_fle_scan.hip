@@ -164,7 +164,7 @@ static ips_status launch_pred_w(const uint64_t* enc, int64_t n_rows, const PredA
 
 // The fused nullable leaf (fle_leaf_kernel): one workgroup per quarter rank tile of output words.
 // *taken = false (nothing launched) for the shapes that keep predicate and expand as separate
-// launches: comparisons at w = 32 (the early-pruning predicate reads half the planes).
+// launches: comparisons at w = 32 with IPS_NO_EARLY_PRUNE set.
 template <int W>
 static ips_status launch_leaf_w(const uint64_t* enc, int64_t n_sub, const PredArgs& args, uint64_t* out,
                                 bool* taken, hipStream_t s) {
@@ -173,10 +173,10 @@ static ips_status launch_leaf_w(const uint64_t* enc, int64_t n_sub, const PredAr
   unsigned long long* o = reinterpret_cast<unsigned long long*>(out);
   *taken = true;
   if constexpr (W == 32) {
-    // comparisons of full-width columns read half the planes with the early-pruning predicate
-    // kernel (2^28 rows, 10 % NULL: 133 us as predicate + expand, 186 us here)
+    // comparisons of full-width columns: the kernel prunes early (high planes first); with the
+    // dev switch that turns pruning off they take predicate + expand
     static const bool early = getenv("IPS_NO_EARLY_PRUNE") == nullptr;
-    if (early && args.op != 5) {
+    if (!early && args.op != 5) {
       *taken = false;
       return IPS_OK;
     }

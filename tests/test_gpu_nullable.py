@@ -72,9 +72,12 @@ def test_nullable_leaf_every_width(capi, O, bw):
     k = int(is_set.sum())
     hi = (1 << bw) - 1
     vals = rng.integers(0, hi + 1, k, dtype=np.uint64).astype(np.uint32)
+    c = int(vals[k // 3])
+    if bw == 32:   # stretches of rows that stay undecided after the high 16 planes (early pruning)
+        vals[1000:6000] = (c & 0xFFFF0000) | (vals[1000:6000] & 0xFFFF)
+        vals[50000:50003] = c
     defs, enc = O.fle_encode(is_set.astype(np.uint32), 1), O.fle_encode(vals, bw)
     d_defs, d_enc = dev_words(defs), dev_words(enc)
-    c = int(vals[k // 3])
     long_list = [int(v) for v in vals[:40]]
     out = torch.empty((n + 63) // 64, dtype=torch.int64, device="cuda")
     for op, consts in ((O.OP_LT, c), (O.OP_GE, c), (O.OP_EQ, c), (O.OP_IN, [c, 0, hi]), (O.OP_IN, long_list)):
