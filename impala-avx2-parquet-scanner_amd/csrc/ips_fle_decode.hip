@@ -1,5 +1,7 @@
 // ips_fle_decode.hip -- instantiations + launchers of the full-decode and encode kernels for the
 // bit widths [IPS_WLO, IPS_WLO+7] (compiled four times so the build parallelises).
+#include <stdlib.h>
+
 #include "ips_fle_kernels.h"
 #include "ips_host.h"
 
@@ -21,9 +23,44 @@ static ips_status launch_decode_one(const uint64_t* enc, int64_t n_rows, void* o
   int grid = grid_for_tiles(reinterpret_cast<const void*>(kern), tiles);
   if (grid <= 0) return IPS_ERR_HIP;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, s, enc, n_rows, out,
-                     reinterpret_cast<const GT*>(dict), dict_entries, bad_index);
+                     reinterpret_cast<const GT*>(dict), dict_entries, bad_index, 0u);
   IPS_HIP_TRY(hipGetLastError());
   return IPS_OK;
+}
+
+// Dictionaries beyond the 32 KiB a workgroup copies for itself: one workgroup of BW waves per CU
+// shares a copy in dynamic LDS -- the whole dictionary if it fits next to the waves' images, else
+// its first lds_entries entries (the rest is gathered from L2 as before).
+constexpr size_t kLdsPerCu = 160 * 1024;
+template <int W, int G, int BW, bool TAIL = false>
+static ips_status launch_decode_shared(const uint64_t* enc, int64_t n_rows, void* out, const void* dict,
+                                       uint32_t dict_entries, int32_t* bad_index, hipStream_t s) {
+  using GT = typename GatherT<G>::type;
+  auto kern = fle_decode_kernel<W, 4, G, BW, true, TAIL>;
+  const size_t room = kLdsPerCu - (size_t)BW * DecodeLds<W, 4, G>::kWaveBytes - 64;  // next to the static images
+  const size_t fit = room / G;
+  const uint32_t lds_entries = dict_entries < fit ? dict_entries : (uint32_t)fit;
+  const size_t dyn = ((size_t)lds_entries * G + 15) & ~(size_t)15;
+  static bool attr_set = false;  // (idempotent; a race sets it twice)
+  if (!attr_set) {
+    IPS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)room));
+    attr_set = true;
+  }
+  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int64_t want = (tiles + BW - 1) / BW;
+  const int64_t cus = device_cus();
+  const int grid = (int)(want < cus ? want : cus);  // persistent: one workgroup per CU
+  if (grid <= 0) return IPS_ERR_HIP;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(BW * kWave), dyn > room ? room : dyn, s, enc, n_rows, out,
+                     reinterpret_cast<const GT*>(dict), dict_entries, bad_index, lds_entries);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+// does the whole dictionary fit next to the images of bw waves?
+template <int W, int G>
+static bool shared_dict_fits(int bw, uint32_t dict_entries) {
+  return (size_t)bw * DecodeLds<W, 4, G>::kWaveBytes + (size_t)dict_entries * G + 80 <= kLdsPerCu;
 }
 
 template <int W>
@@ -44,6 +81,24 @@ static ips_status launch_decode_w(int out_width, int gather, const uint64_t* enc
     return IPS_ERR_INVALID_ARG;
   }
   if constexpr (W <= 16) {
+    if constexpr (W >= 12) {  // dictionaries that may exceed the private 32 KiB copy
+      static const bool shared_off = getenv("IPS_NO_SHARED_DICT") != nullptr;  // dev switch for A/B runs
+      if (!shared_off && (size_t)dict_entries * (size_t)gather > (size_t)kDecodeDictLdsBytes && n_rows >= (1 << 20)) {
+        // as many waves as leave room for the whole dictionary; the largest ones (e.g. 40000 int32
+        // entries) go with four waves and keep their tail in L2
+        if (gather == 4) {
+          if (shared_dict_fits<W, 4>(16, dict_entries)) return launch_decode_shared<W, 4, 16>(enc, n_rows, out, dict, dict_entries, bad_index, s);
+          if (shared_dict_fits<W, 4>(8, dict_entries)) return launch_decode_shared<W, 4, 8>(enc, n_rows, out, dict, dict_entries, bad_index, s);
+          if (shared_dict_fits<W, 4>(4, dict_entries)) return launch_decode_shared<W, 4, 4>(enc, n_rows, out, dict, dict_entries, bad_index, s);
+          return launch_decode_shared<W, 4, 4, true>(enc, n_rows, out, dict, dict_entries, bad_index, s);
+        } else if (gather == 8) {
+          if (shared_dict_fits<W, 8>(16, dict_entries)) return launch_decode_shared<W, 8, 16>(enc, n_rows, out, dict, dict_entries, bad_index, s);
+          if (shared_dict_fits<W, 8>(8, dict_entries)) return launch_decode_shared<W, 8, 8>(enc, n_rows, out, dict, dict_entries, bad_index, s);
+          if (shared_dict_fits<W, 8>(4, dict_entries)) return launch_decode_shared<W, 8, 4>(enc, n_rows, out, dict, dict_entries, bad_index, s);
+          return launch_decode_shared<W, 8, 4, true>(enc, n_rows, out, dict, dict_entries, bad_index, s);
+        }
+      }
+    }
     if (gather == 4)
       return launch_decode_one<W, 4, 4>(enc, n_rows, out, dict, dict_entries, bad_index, s);
     if (gather == 8)

@@ -1364,34 +1364,57 @@ struct DecodeLds {
   static_assert(!kPacked || plane_tile_bytes(W) <= kWaveBytes, "the plane image fits");
 };
 
-template <int W, int OW, int G>
-__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_decode_kernel(
+// BW = waves per workgroup.  The default (4) keeps a private copy of a dictionary of up to 32 KiB
+// per workgroup.  SHARED is the variant for larger dictionaries: ONE workgroup of 16 / 8 / 4 waves
+// per CU whose waves share a single copy in dynamic LDS (dict_entries * G bytes, up to ~140 KiB
+// next to the waves' 3-5 KiB images) instead of gathering every row from L2 (D = 16384 int32:
+// 741 -> 314 us).
+template <int W, int OW, int G, int BW = kWavesPerBlock, bool SHARED = (BW != kWavesPerBlock), bool TAIL = false>
+__global__ __launch_bounds__(BW * kWave, SHARED ? 1 : IPS_MIN_WAVES_PER_EU) void fle_decode_kernel(
     const uint64_t* __restrict__ enc, int64_t n_rows, void* __restrict__ out,
     const typename GatherT<G>::type* __restrict__ dict, uint32_t dict_entries,
-    int32_t* __restrict__ bad_index) {
+    int32_t* __restrict__ bad_index, uint32_t lds_entries) {
   constexpr bool kPackedOut = DecodeLds<W, OW, G>::kPacked;
   constexpr int kDecWaveBytes = DecodeLds<W, OW, G>::kWaveBytes;
-  __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * kDecWaveBytes / 4];
+  constexpr bool kSharedDict = SHARED;
+  __shared__ __attribute__((aligned(16))) uint32_t lds_all[BW * kDecWaveBytes / 4];
   using GT = typename GatherT<G>::type;
-  __shared__ GT dict_lds[DictLds<W, G, kDecodeDictLdsBytes>::kEntries];
+  constexpr bool kPrivateDict = !kSharedDict && DictLds<W, G, kDecodeDictLdsBytes>::kUse;
+  __shared__ GT dict_lds[kPrivateDict ? DictLds<W, G, kDecodeDictLdsBytes>::kEntries : 1];
+  extern __shared__ __attribute__((aligned(16))) uint8_t dict_dyn_bytes[];
+  const GT* dict_dyn = reinterpret_cast<const GT*>(dict_dyn_bytes);
   constexpr int L = (16 * W + kWave - 1) / kWave;
   const int lane = lane_id();
   const int wave = wave_id();
   uint32_t* lds32 = lds_all + wave * (kDecWaveBytes / 4);
-  if constexpr (DictLds<W, G, kDecodeDictLdsBytes>::kUse) {
+  if constexpr (kSharedDict) {
+    // the first lds_entries entries (all of them when the dictionary fits: the reference's largest
+    // int32 dictionary, 40000 entries = 160 000 bytes, leaves no room for a wave's image, so its
+    // last tenth stays in L2)
+    GT* dst = reinterpret_cast<GT*>(dict_dyn_bytes);
+    for (uint32_t i = threadIdx.x; i < lds_entries; i += BW * kWave) dst[i] = dict[i];
+    __syncthreads();
+  } else if constexpr (kPrivateDict) {
     for (uint32_t i = threadIdx.x; i < dict_entries && i < (uint32_t)DictLds<W, G, kDecodeDictLdsBytes>::kEntries; i += kThreads)
       dict_lds[i] = dict[i];
     __syncthreads();
   }
   auto lookup = [&](uint32_t code) -> GT {
-    if constexpr (DictLds<W, G, kDecodeDictLdsBytes>::kUse) return dict_lds[code];
+    if constexpr (kSharedDict && TAIL) {  // a dictionary that does not fit: its tail is gathered from L2
+      GT v = dict_dyn[code < lds_entries ? code : 0u];
+      if (code >= lds_entries) v = dict[code];
+      return v;
+    } else if constexpr (kSharedDict) {
+      return dict_dyn[code];
+    }
+    else if constexpr (kPrivateDict) return dict_lds[code];
     else return dict[code];
   };
 
   const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   const int64_t total_words = ((n_rows + 63) / 64) * W;
-  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
-  int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  const int64_t stride = (int64_t)gridDim.x * BW;
+  int64_t tile = (int64_t)blockIdx.x * BW + wave;
 
   u32x4 r[L];
   if (tile < tiles) tile_load<L, IPS_DECODE_NT_LOADS>(enc, tile, W, total_words, lane, r);

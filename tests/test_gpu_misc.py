@@ -706,3 +706,25 @@ def test_between_on_a_32_bit_column(capi, O):
         nodes = [L(0, ops[0], int(lo)), L(0, ops[1], int(hi)), joiner()]
         got = bits_of(words(capi.eval_program(nodes, cols, n)), n)
         assert np.array_equal(got, truth), ops
+
+
+@pytest.mark.parametrize("type_name,D,bw", [("T_INT32", 12000, 14), ("T_INT32", 20000, 15), ("T_INT32", 30000, 15),
+                                            ("T_INT32", 35000, 16), ("T_INT64", 6000, 13), ("T_INT64", 15000, 14), ("T_INT64", 17000, 15), ("T_INT32", 40000, 16), ("T_INT64", 40000, 16)])
+def test_dictionary_decode_with_a_shared_lds_dictionary(capi, O, type_name, D, bw):
+    """DictDecoder::GetValue x n for dictionaries larger than the 32 KiB a workgroup copies for itself:
+    from 2^20 rows on, one workgroup of 16 / 8 / 4 waves per CU shares a copy in dynamic LDS when it fits
+    (the largest, D = 40000, keep the entries that do not fit in L2); ragged size, every entry hit,
+    bad_index stays 0."""
+    t = getattr(O, type_name)
+    npt = O.NP_TYPES[t]
+    rng = np.random.default_rng(D)
+    n = (1 << 20) + 12345
+    entries = np.sort(rng.choice(np.arange(-10 ** 9, 10 ** 9, 3), D, replace=False)).astype(npt)
+    codes = rng.integers(0, D, n).astype(np.uint32)
+    codes[:D] = np.arange(D, dtype=np.uint32)
+    dd = capi.Dict(entries.view(np.uint8), t)
+    enc = dev_words(O.fle_encode(codes, bw))
+    out, bad = dd.decode(enc, n, bw)
+    assert int(bad.item()) == 0
+    assert np.array_equal(out.cpu().numpy().astype(npt), entries[codes])
+    dd.close()
