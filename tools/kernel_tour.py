@@ -117,6 +117,17 @@ run("assemble_tuples 3 x int32 -> 16 B", "assemble_small_kernel<16>", nsel * 28 
     lambda: lib.ips_assemble_tuples(tc, 3, P(counts), N, 16, None, P(tuples), P(cnt), P(ws), S))
 del vals, enc, outs, bm50, acc, tuples, dense
 
+# dictionary decode with a dictionary shared by one workgroup per CU (beyond 32 KiB), and the largest one
+for Db, bwb, kname in ((16384, 14, "fle_decode_kernel<14, 4, 4, 16"), (40000, 16, "fle_decode_kernel<16, 4, 4, 4")):
+    rngb = np.random.default_rng(Db)
+    dvb = np.sort(rngb.choice(np.arange(-2 ** 30, 2 ** 30, 7), Db, replace=False)).astype(np.int32)
+    cb = ((capi.synth_u32(ips.synth.SEED_DICT, n, 32).to(torch.int64) & 0xFFFFFFFF) % Db).to(torch.int32)
+    eb = capi.fle_encode(cb, bwb)
+    ddb = capi.Dict(dvb.view(np.uint8), capi.T_INT32)
+    run(f"dict_decode D={Db} w={bwb} int32 (shared LDS dictionary)", kname, bwb * 8 * W + 4 * n, lambda: ddb.decode(eb, n, bwb))
+    ddb.close()
+    del cb, eb
+
 # dictionary: decode (gather), IN scan, encode
 D = 4096
 rng = np.random.default_rng(4)
@@ -124,7 +135,7 @@ dict_vals = np.sort(rng.choice(np.arange(-2 ** 30, 2 ** 30, 7), D, replace=False
 codes = ((capi.synth_u32(ips.synth.SEED_DICT, n, 32).to(torch.int64) & 0xFFFFFFFF) % D).to(torch.int32)
 enc = capi.fle_encode(codes, 12)
 dd = capi.Dict(dict_vals.view(np.uint8), capi.T_INT32)
-run("dict_decode D=4096 w=12 int32", "fle_decode_kernel<12, 4, 4>", 12 * 8 * W + 4 * n, lambda: dd.decode(enc, n, 12))
+run("dict_decode D=4096 w=12 int32", "fle_decode_kernel<12, 4, 4, 4", 12 * 8 * W + 4 * n, lambda: dd.decode(enc, n, 12))
 present = rng.choice(D, 8, replace=False)
 lits = np.concatenate([dict_vals[present], dict_vals[present] + 1]).astype(np.int32)
 r0 = dd.scan(enc, n, 12, capi.OP_IN, lits)
