@@ -728,3 +728,33 @@ def test_dictionary_decode_with_a_shared_lds_dictionary(capi, O, type_name, D, b
     assert int(bad.item()) == 0
     assert np.array_equal(out.cpu().numpy().astype(npt), entries[codes])
     dd.close()
+
+
+@pytest.mark.parametrize("type_name", ["T_INT32", "T_INT64"])
+@pytest.mark.parametrize("D,bw", [(200, 8), (1000, 10), (4096, 12), (9000, 14), (20000, 15)])
+def test_dictionary_scan_dense_selections(capi, O, type_name, D, bw):
+    """ips_dict_scan / ips_dict_select on sub-tiles where most or all rows are selected (the dense
+    paths: four gathered entries per lane and 16-byte store while the dictionary sits in LDS or L1,
+    one entry per lane beyond), against numpy; a code outside the dictionary raises bad_index."""
+    t = getattr(O, type_name)
+    npt = O.NP_TYPES[t]
+    rng = np.random.default_rng(D + bw)
+    n = 30011
+    entries = np.sort(rng.choice(np.arange(-10 ** 8, 10 ** 8, 3), D, replace=False)).astype(npt)
+    codes = rng.integers(0, D, n).astype(np.uint32)
+    dd = capi.Dict(entries.view(np.uint8), t)
+    enc = dev_words(O.fle_encode(codes, bw))
+    vals = entries[codes]
+    for frac in (0.5, 0.9, 1.0):
+        lit = entries[min(int(frac * D), D - 1)]
+        op, keep = (capi.OP_LE, vals <= entries[-1]) if frac >= 1.0 else (capi.OP_LT, vals < lit)
+        bitmap, bvals, counts = dd.scan(enc, n, bw, op, np.array([entries[-1] if frac >= 1.0 else lit], dtype=npt))
+        c = counts.cpu().numpy()
+        bv = bvals.cpu().numpy()
+        dense = np.concatenate([bv[b * 2048: b * 2048 + c[b]] for b in range(len(c))])
+        assert np.array_equal(dense.astype(npt), vals[keep]), (D, bw, frac)
+        sv, sc = dd.select(enc, n, bw, bitmap)
+        scn, svn = sc.cpu().numpy(), sv.cpu().numpy()
+        dense2 = np.concatenate([svn[b * 2048: b * 2048 + scn[b]] for b in range(len(scn))])
+        assert np.array_equal(dense2.astype(npt), vals[keep]), (D, bw, frac)
+    dd.close()
