@@ -24,6 +24,12 @@
 
 #include "ips_host.h"
 
+// dev: IPS_PLAIN_ABLATE=1 drops the value stores of the fused scan, =2 the whole materialisation
+// (timing only, results are wrong)
+#ifndef IPS_PLAIN_ABLATE
+#define IPS_PLAIN_ABLATE 0
+#endif
+
 namespace ips {
 
 template <typename T>
@@ -202,7 +208,7 @@ __device__ __forceinline__ void plain_materialise(const uint8_t* lds, uint16_t* 
       const uint32_t i = rd * kWave + lane;
       if (i >= nwin) continue;
       const uint32_t e = list[i];
-      dst[win0 + i] = *reinterpret_cast<const S*>(lds + (e >> 5) * kPlainLaneStride + (e & 31u) * sizeof(S));
+      if (IPS_PLAIN_ABLATE != 1) dst[win0 + i] = *reinterpret_cast<const S*>(lds + (e >> 5) * kPlainLaneStride + (e & 31u) * sizeof(S));
     }
     wave_lds_fence();  // the list is rewritten by the next window
   }
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(kThreads) void plain_tile_kernel(const S* __restric
         const uint32_t mine = (uint32_t)__builtin_popcount(m);
         const uint32_t incl = wave_inclusive_scan(mine);
         count = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        plain_materialise<S>(lds, list, lane, m, incl - mine, count,
+        if (IPS_PLAIN_ABLATE != 2) plain_materialise<S>(lds, list, lane, m, incl - mine, count,
                              batch_values + (tile / G::TPB) * kRowsPerTile + base);
       }
       const bool last_of_batch = G::TPB == 1 || (tile & 1) != 0 || tile + 1 >= n_tiles;
