@@ -255,7 +255,7 @@ __device__ __forceinline__ void fle_scan_body(
     }
 
 #ifndef IPS_ABLATE
-#define IPS_ABLATE 0  // dev: 1 no phase A/B, 2 nothing after the bitmap store, 3 no phase B (results are wrong)
+#define IPS_ABLATE 0  // dev: 1 no phase A/B, 2 nothing after the bitmap store, 3 no phase B, 4 phase B without its stores (results are wrong)
 #endif
     uint32_t count = 0;
     if (IPS_ABLATE != 2 && __builtin_amdgcn_ballot_w64(bm != 0u) != 0ull) {  // wave-uniform: any row selected
@@ -386,7 +386,9 @@ __device__ __forceinline__ void fle_scan_body(
 #define IPS_NT_VALUE_STORE 0
 #endif
         auto put = [&](uint32_t i, uint32_t x) {
-          if (G == 0) {
+          if (IPS_ABLATE == 4) {  // dev: phase B without its value stores
+            if (x == 0xFFFFFFFFu && i == 0x7FFFFFFFu) dst[0] = (GT)x;
+          } else if (G == 0) {
             if (IPS_NT_VALUE_STORE) __builtin_nontemporal_store((GT)x, dst + i);
             else dst[i] = (GT)x;
           } else if (x < dict_entries) {
