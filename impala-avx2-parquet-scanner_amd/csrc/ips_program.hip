@@ -571,8 +571,9 @@ struct NullableCtx {
   uint64_t* sub = nullptr;
 };
 
+// carry: an OPTIONAL column whose tile counts ride on this (REQUIRED FLE) leaf's launch, or NULL
 ips_status emit_item(const ChainItem& it, int combine, const ips_column* cols, int64_t n_rows,
-                     uint64_t* d_bitmap, NullableCtx& nctx, hipStream_t s) {
+                     uint64_t* d_bitmap, NullableCtx& nctx, hipStream_t s, NullableCol* carry = nullptr) {
   const ips_column& c = cols[it.a->column];
   if (c.encoding == IPS_COL_FLE) {
     PredArgs args;
@@ -615,6 +616,10 @@ ips_status emit_item(const ChainItem& it, int combine, const ips_column* cols, i
       }
       return launch_expand(nc.root_kind, nc.root, nctx.sub, n_rows, n_sub, nc.tile_counts, d_bitmap,
                            combine, s);
+    }
+    if (carry && !carry->counted) {  // the counting workgroups of a later nullable leaf, for free
+      attach_rank_counts(&args, carry->root_kind, carry->root, n_rows, carry->tile_counts);
+      carry->counted = true;
     }
     return launch_fle_pred(c.bit_width, reinterpret_cast<const uint64_t*>(c.d_data), n_rows, args,
                            reinterpret_cast<uint32_t*>(d_bitmap), s);
@@ -736,10 +741,32 @@ ips_status run_plan(const Plan& pl, const ips_node* nodes, int n_nodes, const ip
     if (slot == pl.root) return d_bitmap;
     return reinterpret_cast<uint64_t*>(temp + slot_bytes * (size_t)(slot < pl.root ? slot : slot - 1));
   };
+  // The tile counts of an OPTIONAL column are needed by its first leaf; if a leaf on a REQUIRED FLE
+  // column runs before it, the counting workgroups ride on that launch (PredArgs::aux_*) instead of
+  // being a launch of their own in front of the nullable leaf.
+  int carry_col[2 * IPS_PROGRAM_MAX_NODES];
+  for (int i = 0; i < pl.n_steps; ++i) carry_col[i] = -1;
+  static const bool carry_off = getenv("IPS_NO_COUNT_CARRY") != nullptr;  // dev switch for A/B runs
+  for (int c = 0; c < n_cols && !carry_off; ++c) {
+    if (cols[c].max_def_level <= 0) continue;
+    int first = -1;
+    for (int i = 0; i < pl.n_steps && first < 0; ++i)
+      if (pl.steps[i].kind == 0 && pl.steps[i].item.a->column == c) first = i;
+    for (int j = first - 1; j >= 0; --j) {
+      const Step& q = pl.steps[j];
+      if (q.kind != 0 || carry_col[j] >= 0) continue;
+      const ips_column& qc = cols[q.item.a->column];
+      if (qc.encoding == IPS_COL_FLE && qc.max_def_level == 0) {
+        carry_col[j] = c;
+        break;
+      }
+    }
+  }
   ips_status st = IPS_OK;
   for (int i = 0; i < pl.n_steps && st == IPS_OK; ++i) {
     const Step& p = pl.steps[i];
-    if (p.kind == 0) st = emit_item(ChainItem{false, p.item.a, p.item.b, p.item.join}, p.combine, cols, n_rows, slot_ptr(p.dst), nctx, s);
+    if (p.kind == 0) st = emit_item(ChainItem{false, p.item.a, p.item.b, p.item.join}, p.combine, cols, n_rows, slot_ptr(p.dst), nctx, s,
+                                    carry_col[i] >= 0 ? &nctx.col[carry_col[i]] : nullptr);
     else st = launch_bitmap_binop(p.combine == 1 ? 0 : 1, slot_ptr(p.dst), slot_ptr(p.src), (n_rows + 63) / 64, s);
   }
   return st;
