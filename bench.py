@@ -99,6 +99,33 @@ def leg_widths(ips, capi, dev, n):
     return out
 
 
+def leg_plain_twin(ips, capi, dev, n):
+    """configs[0]/[1], the PLAIN twin: the headline column as little-endian int32 slots, LT with the
+    reference's reversed operands (parquet-common.h:208-217) and with SQL's; predicate and fused scan."""
+    out = []
+    page = capi.synth_u32(ips.synth.SEED_HEADLINE, n, 32, device=dev)   # int32 slots (signed)
+    c = int(ips.synth.lt_constant(32))
+    W = (n + 63) // 64
+    for sem, name in ((capi.SEM_REFERENCE, "REFERENCE (literal < x)"), (capi.SEM_SQL, "SQL (x < literal)")):
+        exp = int(((page > c) if sem == capi.SEM_REFERENCE else (page < c)).sum().item())
+        bm = torch.empty(W, dtype=torch.int64, device=dev)
+        tmed, tmin = time_launches(lambda: capi.plain_pred(page, n, capi.T_INT32, capi.OP_LT, np.int32(c), sem, bitmap=bm))
+        out.append(rec(f"configs[1] PLAIN int32 twin, LT {name}: predicate", n, 4 * n + 8 * W, tmed, tmin,
+                       capi.bitmap_count(bm, n) == exp, selectivity=round(exp / n, 4)))
+        res = {}
+
+        def f():
+            res["r"] = capi.plain_scan(page, n, capi.T_INT32, capi.OP_LT, np.int32(c), semantics=sem)
+        tmed, tmin = time_launches(f, reps=6)
+        bm2, bv, cnt = res["r"]
+        n_sel = int(cnt.to(torch.int64).sum().item())
+        out.append(rec(f"configs[1] PLAIN int32 twin, LT {name}: fused scan (bitmap + selected slots)", n,
+                       4 * n + 8 * W + 4 * n_sel, tmed, tmin, bool(n_sel == exp and torch.equal(bm2, bm)),
+                       selectivity=round(n_sel / n, 4)))
+        del res, bm2, bv, cnt
+    return out
+
+
 def leg_config2(ips, capi, dev, n):
     """configs[2]: int64 -- PLAIN 8 B/row and dictionary D = 4096 (w = 12); BETWEEN @10 %."""
     out = []
@@ -117,7 +144,14 @@ def leg_config2(ips, capi, dev, n):
     exp = int(((plain64 >= lo) & (plain64 <= hi)).sum().item())
     out.append(rec("configs[2] PLAIN int64 BETWEEN @10% (one pass, And(Ge,Le))", n, 8 * n + n // 8, tmed, tmin,
                    capi.bitmap_count(bm, n) == exp, selectivity=round(exp / n, 4)))
-    del plain64
+    # the second form SURVEY 8d names: And(Gt a, Lt b) (simple-predicates.h:145-153)
+    nodes = [capi.plain_leaf(0, capi.OP_GT, np.int64(lo - 1), capi.T_INT64),
+             capi.plain_leaf(0, capi.OP_LT, np.int64(hi + 1), capi.T_INT64), capi.and_node()]
+    bm_gl = torch.empty(W, dtype=torch.int64, device=dev)
+    tmed, tmin = time_launches(lambda: capi.eval_program(nodes, cols, n, bitmap=bm_gl))
+    out.append(rec("configs[2] PLAIN int64 And(Gt a, Lt b) @10% (one pass)", n, 8 * n + n // 8, tmed, tmin,
+                   bool(torch.equal(bm_gl, bm)), selectivity=round(exp / n, 4)))
+    del plain64, bm_gl
     D = 4096
     rng = np.random.default_rng(3)
     dict_vals = np.sort(rng.choice(np.arange(-2 ** 40, 2 ** 40, 2 ** 18), D, replace=False)).astype(np.int64)
@@ -134,6 +168,15 @@ def leg_config2(ips, capi, dev, n):
     exp = int(((codes >= lo_c) & (codes < hi_c)).sum().item())
     out.append(rec("configs[2] dictionary int64 D=4096 w=12 BETWEEN @10%", n, 12 * 8 * W + 8 * W + D * 8, tmed, tmin,
                    capi.bitmap_count(bm, n) == exp, selectivity=round(exp / n, 4)))
+    # And(Gt a, Lt b) with a, b between dictionary entries: DictDecoder::Gt -> Ge(upper_bound),
+    # ::Lt -> Lt(lower_bound) (dict-encoding.h:473-495); the same rows as the BETWEEN above
+    _, op_a, c_a = dd.translate(capi.OP_GT, lo - 1)
+    _, op_b, c_b = dd.translate(capi.OP_LT, hi + 1)
+    nodes = [capi.leaf(0, op_a, c_a), capi.leaf(0, op_b, c_b), capi.and_node()]
+    bm_gl = torch.empty(W, dtype=torch.int64, device=dev)
+    tmed, tmin = time_launches(lambda: capi.eval_program(nodes, cols, n, bitmap=bm_gl))
+    out.append(rec("configs[2] dictionary int64 D=4096 w=12 And(Gt a, Lt b) @10%", n, 12 * 8 * W + 8 * W + D * 8,
+                   tmed, tmin, bool(torch.equal(bm_gl, bm)), selectivity=round(exp / n, 4)))
     dd.close()
     return out
 
@@ -567,7 +610,8 @@ def main():
         del enc
         torch.cuda.empty_cache()
         configs = []
-        for leg in (lambda: leg_widths(ips, capi, dev, n), lambda: leg_config2(ips, capi, dev, n),
+        for leg in (lambda: leg_widths(ips, capi, dev, n), lambda: leg_plain_twin(ips, capi, dev, n),
+                    lambda: leg_config2(ips, capi, dev, n),
                     lambda: leg_config3(ips, capi, dev, n), lambda: leg_nullable(capi, dev, n),
                     lambda: leg_q6_single(ips, capi, dev, O)):
             try:

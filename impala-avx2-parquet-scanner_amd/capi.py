@@ -46,7 +46,7 @@ SYMBOLS = [
     "ips_plain_stride", "ips_plain_pred", "ips_plain_scan", "ips_plain_select",
     "ips_bitmap_and", "ips_bitmap_or", "ips_bitmap_fill", "ips_bitmap_count",
     "ips_expand_workspace_bytes", "ips_bitmap_expand",
-    "ips_eval_program", "ips_synth_splitmix_u32",
+    "ips_eval_program", "ips_set_program_strategy", "ips_synth_splitmix_u32",
     "ips_comm_unique_id", "ips_comm_init", "ips_comm_destroy", "ips_allgather_bitmap",
     "ips_fle_scan_allgather", "ips_comm_join",
 ]
@@ -553,6 +553,13 @@ def plain_column(page, type_):
     c = Column()
     c.encoding, c.bit_width, c.type, c.d_data = COL_PLAIN, 0, type_, page.data_ptr()
     return c
+
+
+PROGRAM_AUTO, PROGRAM_PER_OPERAND, PROGRAM_ONE_PASS, PROGRAM_ONE_LAUNCH = range(4)
+
+
+def set_program_strategy(strategy):
+    _ck(lib().ips_set_program_strategy(int(strategy)))
 
 
 def program_workspace_bytes(nodes, cols, n_rows):

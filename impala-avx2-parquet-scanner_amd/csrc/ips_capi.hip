@@ -55,7 +55,7 @@ int device_cus() {
 // neutral at w=32 and 3-5 % faster at w <= 16, 12x and more cost the early-pruning predicate its
 // prefetch).  IPS_GRID_MULT overrides it (dev knob).
 int grid_mult() {
-  static int m = [] { const char* e = getenv("IPS_GRID_MULT"); int v = e ? atoi(e) : 8; return v > 0 ? v : 8; }();
+  static int m = [] { const char* e = dev_env("IPS_GRID_MULT"); int v = e ? atoi(e) : 8; return v > 0 ? v : 8; }();
   return m;
 }
 
@@ -159,7 +159,7 @@ ips_status launch_fle_pred(int w, const uint64_t* enc, int64_t n_rows, const Pre
 }
 
 bool fused_leaf_enabled() {  // dev switch for A/B runs
-  static const bool on = getenv("IPS_NO_FUSED_LEAF") == nullptr;
+  static const bool on = dev_env("IPS_NO_FUSED_LEAF") == nullptr;
   return on;
 }
 
@@ -867,7 +867,7 @@ struct SelNullWs {
 };
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 bool select_nullable_one_pass() {  // dev switch for A/B runs: IPS_SELECT_NULLABLE_STEPS=1 composes the call from ten launches
-  static const bool on = getenv("IPS_SELECT_NULLABLE_STEPS") == nullptr;
+  static const bool on = dev_env("IPS_SELECT_NULLABLE_STEPS") == nullptr;
   return on;
 }
 SelNullWs sel_null_ws(void* base, int64_t n_rows, int64_t n_data_rows, int value_width) {

@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "ips_bitops.h"
+#include "ips_knobs.h"
 
 namespace ips {
 
@@ -25,9 +26,6 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = kWave * kWavesPerBlock;
-#ifndef IPS_MIN_WAVES_PER_EU
-#define IPS_MIN_WAVES_PER_EU 3
-#endif
 
 // Predicate parameters travel in the kernarg segment: wave-uniform, read with scalar loads.
 struct PredArgs {
@@ -106,9 +104,6 @@ __device__ __forceinline__ u32x4 stream_load(const u32x4* p) {
 // whole sub-tile.  (The first version branched to a per-chunk bounds path for the last sub-tile:
 // never executed twice, but its 64-bit addresses and conditions cost every FLE kernel about 34
 // VGPRs of allocation -- fle_scan_kernel<32>: 150 -> 116 = 4 waves per SIMD instead of 3.)
-#ifndef IPS_BUFFER_LOADS
-#define IPS_BUFFER_LOADS 1
-#endif
 constexpr unsigned kBufferRsrcDword3 = 0x00020000u;  // gfx9 family: DATA_FORMAT_32, raw (unswizzled) buffer
 
 template <bool NT = true>
@@ -133,38 +128,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const uint64_t* __re
 template <int MAXLOADS, bool NT = true>
 __device__ __forceinline__ void tile_load(const uint64_t* __restrict__ enc, int64_t tile, int w,
                                           int64_t total_words, int lane, u32x4 (&r)[MAXLOADS]) {
-#if IPS_BUFFER_LOADS
   const __amdgpu_buffer_rsrc_t rsrc = tile_rsrc(enc, tile, w, total_words);
 #pragma unroll
   for (int i = 0; i < MAXLOADS; ++i) r[i] = buffer_load16<NT>(rsrc, (uint32_t)(i * kWave + lane) * 16u);
-#else
-  const int64_t w0 = tile * (int64_t)(kBlocksPerTile * w);
-  const int chunks = 16 * w;
-  const uint64_t* base = enc + w0;
-  if (w0 + kBlocksPerTile * w <= total_words) {  // wave-uniform: full tile, no per-lane bounds
-#pragma unroll
-    for (int i = 0; i < MAXLOADS; ++i) {
-      int c = i * kWave + lane;
-      if (c < chunks) r[i] = stream_load<NT>(reinterpret_cast<const u32x4*>(base + 2 * c));
-    }
-  } else {
-    const int64_t left = total_words - w0;  // words available in this (last) tile
-#pragma unroll
-    for (int i = 0; i < MAXLOADS; ++i) {
-      int c = i * kWave + lane;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (c < chunks) {
-        if (2 * c + 1 < left) {
-          v = *reinterpret_cast<const u32x4*>(base + 2 * c);
-        } else if (2 * c < left) {
-          u32x2 h = *reinterpret_cast<const u32x2*>(base + 2 * c);
-          v.x = h.x; v.y = h.y;
-        }
-      }
-      r[i] = v;
-    }
-  }
-#endif
 }
 
 // Late materialisation against a given bitmap touches only the blocks that hold a selected row --
@@ -177,7 +143,6 @@ template <int MAXLOADS, int W>
 __device__ __forceinline__ void tile_load_needed(const uint64_t* __restrict__ enc, int64_t tile,
                                                  int64_t total_words, int lane,
                                                  uint64_t need_blocks, u32x4 (&r)[MAXLOADS]) {
-#if IPS_BUFFER_LOADS
   const __amdgpu_buffer_rsrc_t rsrc = tile_rsrc(enc, tile, W, total_words);
 #pragma unroll
   for (int i = 0; i < MAXLOADS; ++i) {
@@ -188,23 +153,6 @@ __device__ __forceinline__ void tile_load_needed(const uint64_t* __restrict__ en
         r[i] = buffer_load16<true>(rsrc, (uint32_t)c * 16u);
     }
   }
-#else
-  const int64_t w0 = tile * (int64_t)(kBlocksPerTile * W);
-  if (w0 + kBlocksPerTile * W > total_words) {  // last, partial sub-tile: the guarded plain path
-    tile_load<MAXLOADS, true>(enc, tile, W, total_words, lane, r);
-    return;
-  }
-  const uint64_t* base = enc + w0;
-#pragma unroll
-  for (int i = 0; i < MAXLOADS; ++i) {
-    const int c = i * kWave + lane;
-    if (c < 16 * W) {
-      const int b0 = (2 * c) / W, b1 = (2 * c + 1) / W;
-      if (((need_blocks >> (2 * b0)) | (need_blocks >> (2 * b1))) & 1ull)
-        r[i] = stream_load<true>(reinterpret_cast<const u32x4*>(base + 2 * c));
-    }
-  }
-#endif
 }
 
 // ---- VGPR -> LDS (odd word stride per block) ------------------------------------------------
@@ -431,13 +379,6 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t x) {
 // conflict-free up to 100 % selectivity (lane l writes element 32*l + j in step j: bank
 // (j + l) mod 32).
 __device__ __forceinline__ uint32_t compact_dw(uint32_t P) { return P + (P >> 5); }
-
-// A sub-tile takes the sparse path when no lane selected more than this many of its 32 rows
-// (always the case up to ~15 % selectivity): 3 rounds of 4 rows.
-#ifndef IPS_SPARSE_LANE_MAX
-#define IPS_SPARSE_LANE_MAX 12
-#endif
-constexpr uint32_t kSparseLaneMax = IPS_SPARSE_LANE_MAX;
 
 // Dense path: each lane appends the selected ones of its own 32 rows (v[j] <-> bit j of bm) behind
 // those of all lower lanes (P = exclusive prefix of the per-lane counts).  32 predicated LDS

@@ -82,7 +82,7 @@ static ips_status launch_decode_w(int out_width, int gather, const uint64_t* enc
   }
   if constexpr (W <= 16) {
     if constexpr (W >= 12) {  // dictionaries that may exceed the private 32 KiB copy
-      static const bool shared_off = getenv("IPS_NO_SHARED_DICT") != nullptr;  // dev switch for A/B runs
+      static const bool shared_off = dev_env("IPS_NO_SHARED_DICT") != nullptr;  // dev switch for A/B runs
       if (!shared_off && (size_t)dict_entries * (size_t)gather > (size_t)kDecodeDictLdsBytes && n_rows >= (1 << 20)) {
         // as many waves as leave room for the whole dictionary; the largest ones (e.g. 40000 int32
         // entries) go with four waves and keep their tail in L2

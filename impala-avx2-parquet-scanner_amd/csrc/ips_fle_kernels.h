@@ -8,14 +8,8 @@
 #include "ips_device.h"
 #include "ips_rank_device.h"
 
-// nt loads in decode / encode pay once their output streams are nt stores as well (-3...-4 %);
-// with plain stores they measured 4 % slower.
-#ifndef IPS_DECODE_NT_LOADS
-#define IPS_DECODE_NT_LOADS true
-#endif
-#ifndef IPS_ENCODE_NT_LOADS
-#define IPS_ENCODE_NT_LOADS true
-#endif
+// (nt loads in decode / encode pay once their output streams are nt stores as well, -3...-4 %;
+// with plain stores they measured 4 % slower: IPS_DECODE_NT_LOADS / IPS_ENCODE_NT_LOADS, ips_knobs.h)
 
 namespace ips {
 
@@ -105,15 +99,6 @@ __device__ __forceinline__ uint32_t in_table_lookup(const uint32_t* table, const
 // waves fill the gaps that LDS round trips and waitcnts leave (w = 8 @10 %: 82 -> 70 us with 4 KiB
 // per wave and 8 waves per SIMD).  The small layouts have no room for the dense compaction image
 // of 2048 dwords: beyond 512 selected rows they compact the lane-packed bytes / halfwords instead.
-#ifndef IPS_SCAN_SMALL_LDS
-#define IPS_SCAN_SMALL_LDS 1
-#endif
-#ifndef IPS_SCAN_SMALL_LDS_MAX_W
-#define IPS_SCAN_SMALL_LDS_MAX_W 8
-#endif
-#ifndef IPS_INDEX_PATH
-#define IPS_INDEX_PATH 1
-#endif
 template <int W, int MODE>
 struct ScanLds {
   // (w = 9..16 with 6 KiB: the 96 registers that 5 waves per SIMD leave spill, and without spills
@@ -121,10 +106,10 @@ struct ScanLds {
   // IN-list scans of w = 9..16 (dictionary codes, a handful of rows selected) do take the small
   // layout, WITHOUT a dense path: beyond 512 selected rows of a sub-tile they work the index list
   // off in windows of 512 (kWindowed) -- slow there, but their registers then fit 5 waves per SIMD.
-  static constexpr bool kWindowed = IPS_SCAN_SMALL_LDS && IPS_INDEX_PATH && MODE == kScanInList && W > IPS_SCAN_SMALL_LDS_MAX_W && W <= 16;
+  static constexpr bool kWindowed = IPS_SCAN_SMALL_LDS && MODE == kScanInList && W > IPS_SCAN_SMALL_LDS_MAX_W && W <= 16;
   // (membership-table scans of w <= 8 as well: the decoded values are only needed for the lookup,
   // what is parked are the lane-packed bytes)
-  static constexpr bool kSmall = IPS_SCAN_SMALL_LDS && IPS_INDEX_PATH &&
+  static constexpr bool kSmall = IPS_SCAN_SMALL_LDS &&
                                  (MODE != kScanInTable ? (W <= IPS_SCAN_SMALL_LDS_MAX_W || kWindowed)
                                                        : W <= IPS_SCAN_SMALL_LDS_MAX_W);
   static constexpr int kBody = !kSmall ? kRowTileBytes : W <= 8 ? 64 * packed_lane_stride(8) : 64 * packed_lane_stride(16);
@@ -254,9 +239,6 @@ __device__ __forceinline__ void fle_scan_body(
       given_nxt = given_nn;
     }
 
-#ifndef IPS_ABLATE
-#define IPS_ABLATE 0  // dev: 1 no phase A/B, 2 nothing after the bitmap store, 3 no phase B, 4 phase B without its stores (results are wrong)
-#endif
     uint32_t count = 0;
     if (IPS_ABLATE != 2 && __builtin_amdgcn_ballot_w64(bm != 0u) != 0ull) {  // wave-uniform: any row selected
       const uint32_t mine = (uint32_t)__builtin_popcount(bm);
@@ -268,15 +250,6 @@ __device__ __forceinline__ void fle_scan_body(
       // out of the plane registers (2 ops per plane and row) instead of transposing all 32 rows
       // and going through the row tile -- a narrow sub-tile is only 256*W bytes of HBM time, so
       // the transposes and the walk are what bounds it.
-      #ifndef IPS_GATHER_WIDE
-#define IPS_GATHER_WIDE 0  // dev knob: rows per lane up to which w > 16 takes this path (measured: off)
-#endif
-#ifndef IPS_GATHER_MAX_4
-#define IPS_GATHER_MAX_4 12
-#define IPS_GATHER_MAX_8 5
-#define IPS_GATHER_MAX_12 3
-#define IPS_GATHER_MAX_16 2
-#endif
       constexpr uint32_t kGatherLaneMax = W <= 4 ? IPS_GATHER_MAX_4 : W <= 8 ? IPS_GATHER_MAX_8 : W <= 12 ? IPS_GATHER_MAX_12
                                         : W <= 16 ? IPS_GATHER_MAX_16 : IPS_GATHER_WIDE;
       if (!kInTable && kGatherLaneMax != 0 &&
@@ -310,18 +283,11 @@ __device__ __forceinline__ void fle_scan_body(
         continue;
       }
       constexpr int R = LaneWidth<W>::R;
-      constexpr bool kPacked = IPS_INDEX_PATH && R < 32;  // values stay lane-packed (table mode too: its decoded dwords are only for the lookup)
-#ifndef IPS_QUADS
-#define IPS_QUADS 1
-#endif
-      constexpr bool kQuads = IPS_QUADS && IPS_INDEX_PATH && !kInTable && R == 32;  // half-transposed in LDS
-#ifndef IPS_QUADS16
-#define IPS_QUADS16 1  // w=16 / 12 / 10 LT @10 %: 134 -> 117 / 127 -> 111 / 114 -> 100 us
-#endif
+      constexpr bool kPacked = R < 32;  // values stay lane-packed (table mode too: its decoded dwords are only for the lookup)
+      constexpr bool kQuads = IPS_QUADS && !kInTable && R == 32;  // half-transposed in LDS
       constexpr bool kQuads16 = IPS_QUADS16 && kPacked && !kInTable && R == 16;
-      const bool index_path = IPS_INDEX_PATH ? (kWindowed || count <= (uint32_t)kIndexListMax)
-                                             : __builtin_amdgcn_ballot_w64(mine > kSparseLaneMax) == 0ull;
-      if (IPS_INDEX_PATH && index_path) {
+      const bool index_path = kWindowed || count <= (uint32_t)kIndexListMax;
+      if (index_path) {
         // Index-list path (up to 25 % selectivity).  The lane parks its 32 values in LDS -- as
         // bytes / halfwords for W <= 8 / 16 (the lane-packed registers as they are: 2 / 4 x 16
         // bytes), as dwords above -- and appends the LDS byte offset of each of ITS selected rows
@@ -356,12 +322,6 @@ __device__ __forceinline__ void fle_scan_body(
         // straight-line round -- lowest set bit, store under the exec mask, clear it -- until no
         // lane has a bit left; finished lanes keep clearing zero.
         uint16_t* list = reinterpret_cast<uint16_t*>(lds8 + (kWB - kIndexListBytes));
-#ifndef IPS_PHASE_A_UNIFORM
-#define IPS_PHASE_A_UNIFORM 1  // trip count = the wave's largest popcount (one DPP max), no ballot per round
-#endif
-#ifndef IPS_PHASE_B_GROUP
-#define IPS_PHASE_B_GROUP 4    // rounds whose LDS reads are issued together
-#endif
         const uint32_t lane5 = (uint32_t)lane << 5;
         int bad = 0;
         auto value_at = [&](uint32_t e) -> uint32_t {
@@ -382,9 +342,6 @@ __device__ __forceinline__ void fle_scan_body(
             return lds8[src * kStride + 4u * ((31u - j) & 7u) + ((31u - j) >> 3)];
           }
         };
-#ifndef IPS_NT_VALUE_STORE
-#define IPS_NT_VALUE_STORE 0
-#endif
         auto put = [&](uint32_t i, uint32_t x) {
           if (IPS_ABLATE == 4) {  // dev: phase B without its value stores
             if (x == 0xFFFFFFFFu && i == 0x7FFFFFFFu) dst[0] = (GT)x;
@@ -421,19 +378,13 @@ __device__ __forceinline__ void fle_scan_body(
           if (IPS_ABLATE != 1) {
             uint32_t m = bm;
             uint16_t* slot = list + P;
-            if (IPS_PHASE_A_UNIFORM) {
-              const uint32_t trips = wave_max(mine);  // scalar loop control: nothing waits for a ballot
-              for (uint32_t t = 0; t < trips; ++t) {
-                if (m != 0u) *slot = (uint16_t)(lane5 | (uint32_t)__builtin_ctz(m));
-                ++slot;
-                m &= m - 1u;
-              }
-            } else {
-              do {
-                if (m != 0u) *slot = (uint16_t)(lane5 | (uint32_t)__builtin_ctz(m));
-                ++slot;
-                m &= m - 1u;
-              } while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull);
+            // trip count = the wave's largest popcount (one DPP max): scalar loop control, nothing
+            // waits for a ballot per round
+            const uint32_t trips = wave_max(mine);
+            for (uint32_t t = 0; t < trips; ++t) {
+              if (m != 0u) *slot = (uint16_t)(lane5 | (uint32_t)__builtin_ctz(m));
+              ++slot;
+              m &= m - 1u;
             }
           }
           wave_lds_fence();
@@ -453,42 +404,6 @@ __device__ __forceinline__ void fle_scan_body(
             wave_lds_fence();
             phase_b(win0, count - win0 < (uint32_t)kIndexListMax ? count - win0 : (uint32_t)kIndexListMax);
             wave_lds_fence();  // the list is rewritten by the next window
-          }
-        }
-        if (G != 0 && bad && bad_index) *bad_index = 1;
-      } else if (!IPS_INDEX_PATH && index_path) {
-        // Round-1 sparse path (dev comparison, IPS_INDEX_PATH=0): each lane parks its 32 values in
-        // its own slot of the row tile and walks the set bits of its mask, four per round,
-        // scattering straight to the batch in HBM.
-        if (!kInTable) planes_to_values<W>(p, v);
-        wave_lds_fence();
-        values_to_row_tile(lds32, lane, v);
-        const uint32_t* mine_lds = lds32 + lane * kRowTileStrideDw;
-        uint32_t m = bm;
-        int bad = 0;
-#pragma unroll 1
-        for (int round = 0; round < (int)kSparseLaneMax / 4; ++round) {
-          if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) break;
-          uint32_t x[4];
-          bool ok[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            ok[e] = m != 0u;
-            x[e] = mine_lds[ok[e] ? __builtin_ctz(m) : 0];
-            m &= m - 1u;
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (ok[e]) {
-              if (G == 0) {
-                dst[P] = (GT)x[e];
-              } else if (x[e] < dict_entries) {
-                dst[P] = lookup(x[e]);
-              } else {
-                bad = 1;
-              }
-              ++P;
-            }
           }
         }
         if (G != 0 && bad && bad_index) *bad_index = 1;
@@ -1276,23 +1191,12 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_ear
 
   // half = 1: words 16..31 of every block (planes 31..16), half = 0: words 0..15
   auto load_half = [&](int64_t tile, int half, u32x4 (&r)[4]) {
-#if IPS_BUFFER_LOADS
     const __amdgpu_buffer_rsrc_t rsrc = tile_rsrc(enc, tile, W, total_words);  // range-checked by the hardware
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ch = i * kWave + lane;                  // 256 chunks of 16 bytes per half tile
       r[i] = buffer_load16<true>(rsrc, (uint32_t)(((ch >> 3) * W + half * 16 + (ch & 7) * 2) * 8));
     }
-#else
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ch = i * kWave + lane;                  // 256 chunks of 16 bytes per half tile
-      const int64_t word = tile * (kBlocksPerTile * W) + (ch >> 3) * W + half * 16 + (ch & 7) * 2;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (word + 1 < total_words) v = stream_load(reinterpret_cast<const u32x4*>(enc + word));
-      r[i] = v;                                         // whole blocks only: words come in pairs
-    }
-#endif
   };
   auto stage_half = [&](int half, const u32x4 (&r)[4]) {
 #pragma unroll
@@ -1390,9 +1294,6 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_ear
 // that every store instruction still writes 1 KiB of consecutive output).  Against the row tile of the general path (every value
 // unpacked to a dword, 32 dword writes + reads per lane): 3 / 5 KiB of LDS per wave instead of 9
 // and about half the VALU (dictionary decode D = 4096, w = 12: 525 -> 2xx per sub-tile).
-#ifndef IPS_DECODE_PACKED
-#define IPS_DECODE_PACKED 1
-#endif
 template <int W, int OW, int G>
 struct DecodeLds {
   static constexpr bool kPacked = IPS_DECODE_PACKED && W <= 16 && G != 0;  // (to plain dwords: no gain, write-bound)

@@ -16,7 +16,7 @@ namespace ips {
 // IN lists of at least this many constants take the membership-table path (dev override:
 // IPS_IN_TABLE_MIN=<K> for every width)
 static int in_table_forced() {
-  static const int forced = [] { const char* e = getenv("IPS_IN_TABLE_MIN"); return e ? atoi(e) : 0; }();
+  static const int forced = [] { const char* e = dev_env("IPS_IN_TABLE_MIN"); return e ? atoi(e) : 0; }();
   return forced;
 }
 static int in_table_min(int w) { return in_table_forced() > 0 ? in_table_forced() : in_table_min_consts(w); }
@@ -141,7 +141,7 @@ template <int W>
 static ips_status launch_pred_w(const uint64_t* enc, int64_t n_rows, const PredArgs& args,
                                 uint32_t* bitmap32, hipStream_t s) {
   if constexpr (W == 32) {
-    static const bool early = getenv("IPS_NO_EARLY_PRUNE") == nullptr;
+    static const bool early = dev_env("IPS_NO_EARLY_PRUNE") == nullptr;
     if (early && args.op != 5) {
       const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
       auto kern = args.join != 0 ? fle_pred32_early_kernel<32, true> : fle_pred32_early_kernel<32, false>;
@@ -175,7 +175,7 @@ static ips_status launch_leaf_w(const uint64_t* enc, int64_t n_sub, const PredAr
   if constexpr (W == 32) {
     // comparisons of full-width columns: the kernel prunes early (high planes first); with the
     // dev switch that turns pruning off they take predicate + expand
-    static const bool early = getenv("IPS_NO_EARLY_PRUNE") == nullptr;
+    static const bool early = dev_env("IPS_NO_EARLY_PRUNE") == nullptr;
     if (!early && args.op != 5) {
       *taken = false;
       return IPS_OK;

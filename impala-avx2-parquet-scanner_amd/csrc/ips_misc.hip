@@ -7,11 +7,8 @@
 
 namespace ips {
 
-// read-once column slots and the 16-byte tuple stream of assemble_tuples (232 -> 207 us); dev knob
-// IPS_AUX_NT=0 turns the hints off
-#ifndef IPS_AUX_NT
-#define IPS_AUX_NT 1
-#endif
+// read-once column slots and the 16-byte tuple stream of assemble_tuples carry the nt hint
+// (232 -> 207 us; IPS_AUX_NT, ips_knobs.h)
 template <typename T>
 __device__ __forceinline__ T aux_load(const T* p) {
   return IPS_AUX_NT ? __builtin_nontemporal_load(p) : *p;

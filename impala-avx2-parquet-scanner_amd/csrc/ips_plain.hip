@@ -24,12 +24,6 @@
 
 #include "ips_host.h"
 
-// dev: IPS_PLAIN_ABLATE=1 drops the value stores of the fused scan, =2 the whole materialisation
-// (timing only, results are wrong)
-#ifndef IPS_PLAIN_ABLATE
-#define IPS_PLAIN_ABLATE 0
-#endif
-
 namespace ips {
 
 template <typename T>
@@ -78,7 +72,6 @@ __device__ __forceinline__ void plain_tile_load(const S* __restrict__ page, int6
                                                 int lane, u32x4 (&r)[kPlainLoads]) {
   using G = PlainGeom<S>;
   const int64_t row0 = tile * G::RT;
-#if IPS_BUFFER_LOADS
   // a buffer resource over the tile's bytes that exist: dwords beyond them read as 0 (ips_device.h)
   int64_t left = (n_rows - row0) * (int64_t)sizeof(S);
   left = left < 0 ? 0 : (left > kPlainTileBytes ? kPlainTileBytes : left);
@@ -87,24 +80,6 @@ __device__ __forceinline__ void plain_tile_load(const S* __restrict__ page, int6
       __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(base), 0, (int)left, kBufferRsrcDword3);
 #pragma unroll
   for (int i = 0; i < kPlainLoads; ++i) r[i] = buffer_load16<true>(rsrc, (uint32_t)(i * kWave + lane) * 16u);
-#else
-  if (row0 + G::RT <= n_rows) {  // wave-uniform: whole tile
-#pragma unroll
-    for (int i = 0; i < kPlainLoads; ++i)
-      r[i] = stream_load<true>(reinterpret_cast<const u32x4*>(page + row0) + i * kWave + lane);
-  } else {
-#pragma unroll
-    for (int i = 0; i < kPlainLoads; ++i) {
-      S e[G::RPL];
-#pragma unroll
-      for (int k = 0; k < G::RPL; ++k) {
-        const int64_t row = row0 + (int64_t)(i * kWave + lane) * G::RPL + k;
-        e[k] = row < n_rows ? page[row] : (S)0;
-      }
-      __builtin_memcpy(&r[i], e, 16);
-    }
-  }
-#endif
 }
 
 // 16-byte piece c of the tile belongs to lane c / 8, piece c % 8 of its 128 bytes

@@ -12,12 +12,14 @@
 #include <mutex>
 #include <utility>
 
-#include <map>
-#include <mutex>
+#include <atomic>
 
 #include "ips_host.h"
 
 namespace ips {
+
+// how ips_eval_program evaluates a tree (ips_set_program_strategy; process-wide, AUTO by default)
+static std::atomic<int> g_program_strategy{IPS_PROGRAM_AUTO};
 
 constexpr int kMaxLeaves = 16;
 constexpr int kStackDepth = 8;
@@ -394,7 +396,7 @@ struct ChainArgs {
 // instructions per cycle.  Hoisting the slot state into scalar registers spilled 126 of them
 // (385 us); lane-owned chunks across operand boundaries with per-lane pointers took 130 VGPRs
 // (430-500 us); one operand's piece in flight at a time: 344 us.  The kernel stays opt-in
-// (IPS_PROGRAM_ONE_PASS=1); closing the gap needs the widths at compile time.
+// (ips_set_program_strategy(IPS_PROGRAM_ONE_PASS)); closing the gap needs the widths at compile time.
 template <int N, int LTOT>
 __global__ __launch_bounds__(kThreads, LTOT <= 8 ? 6 : IPS_MIN_WAVES_PER_EU) void fle_chain_kernel(
     ChainArgs<N> a, int64_t n_rows, uint32_t* __restrict__ bitmap32, int image_dwords, int n_slots) {
@@ -546,7 +548,7 @@ using namespace ips;
 // or ORs its result into a bitmap.  Those kernels run at 70-78 % of the HBM roofline (the
 // measured read ceiling of the part), the single-launch program_kernel at ~20 %, so the extra
 // read-modify-write of the bitmap (2 bits per row and operand) is cheap.  program_kernel stays
-// as the one-launch alternative (IPS_PROGRAM_NO_CHAIN=1).
+// as the one-launch alternative (IPS_PROGRAM_ONE_LAUNCH).
 // ---------------------------------------------------------------------------------------------
 namespace {
 
@@ -746,7 +748,7 @@ ips_status run_plan(const Plan& pl, const ips_node* nodes, int n_nodes, const ip
   // being a launch of their own in front of the nullable leaf.
   int carry_col[2 * IPS_PROGRAM_MAX_NODES];
   for (int i = 0; i < pl.n_steps; ++i) carry_col[i] = -1;
-  static const bool carry_off = getenv("IPS_NO_COUNT_CARRY") != nullptr;  // dev switch for A/B runs
+  static const bool carry_off = dev_env("IPS_NO_COUNT_CARRY") != nullptr;  // dev switch for A/B runs
   for (int c = 0; c < n_cols && !carry_off; ++c) {
     if (cols[c].max_def_level <= 0) continue;
     int first = -1;
@@ -773,6 +775,13 @@ ips_status run_plan(const Plan& pl, const ips_node* nodes, int n_nodes, const ip
 }
 
 }  // namespace
+
+extern "C" ips_status ips_set_program_strategy(int strategy) {
+  IPS_REQUIRE(strategy >= IPS_PROGRAM_AUTO && strategy <= IPS_PROGRAM_ONE_LAUNCH,
+              "ips_set_program_strategy: %d is not an ips_program_strategy", strategy);
+  g_program_strategy.store(strategy, std::memory_order_relaxed);
+  return IPS_OK;
+}
 
 extern "C" size_t ips_program_workspace_bytes(const ips_node* nodes, int n_nodes,
                                               const ips_column* cols, int n_cols, int64_t n_rows) {
@@ -880,14 +889,15 @@ extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const
   IPS_REQUIRE(depth == 1, "ips_eval_program: program leaves %d bitmaps on the stack", depth);
   IPS_REQUIRE(max_depth <= kStackDepth, "ips_eval_program: tree deeper than %d", kStackDepth);
   if (n_rows == 0) return IPS_OK;
-  if (getenv("IPS_PROGRAM_NO_CHAIN") == nullptr) {  // dev knob: force the one-launch kernel
+  const int strategy = g_program_strategy.load(std::memory_order_relaxed);
+  if (strategy != IPS_PROGRAM_ONE_LAUNCH) {
     Plan pl;
     if (make_plan(nodes, n_nodes, &pl)) {
       // a pure chain over REQUIRED FLE columns can run as one pass with one bitmap write
-      // (IPS_PROGRAM_ONE_PASS=1).  Off by default: with run-time widths it is bound by the scalar
+      // (IPS_PROGRAM_ONE_PASS).  Not what AUTO picks: with run-time widths it is bound by the scalar
       // unit and only ties the three per-operand launches on the Q6 shape (see fle_chain_kernel).
       if (pl.n_slots == 1 && !any_nullable && pl.n_steps >= 2 && pl.n_steps <= kChainMaxOps &&
-          getenv("IPS_PROGRAM_ONE_PASS") != nullptr) {
+          strategy == IPS_PROGRAM_ONE_PASS) {
         ChainOp ops[kChainMaxOps];
         bool ok = true;
         int widths[kChainMaxOps];

@@ -16,9 +16,6 @@ constexpr int kRankWordsPerTile = kRankWordsPerWave * kRankWaves;  // 4096 words
 // (4 waves x 2 rounds), so the grid has 4x the blocks of the counting pass -- several generations
 // of workgroups per CU, whose load / deposit / store phases overlap (with one generation of
 // 4096-word blocks every wave of the chip was in the same phase: 38 -> 34 us for 2^28 rows)
-#ifndef IPS_EXP_ROUNDS
-#define IPS_EXP_ROUNDS 2
-#endif
 constexpr int kExpRounds = IPS_EXP_ROUNDS;
 constexpr int kExpWordsPerWave = kWave * 2 * kExpRounds;          // 256 words
 constexpr int kExpWordsPerBlock = kExpWordsPerWave * kRankWaves;   // 1024 words

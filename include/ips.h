@@ -376,6 +376,17 @@ typedef struct {
   uint64_t consts[16];   /* leaf: FLE constants, or PLAIN literal bit patterns */
 } ips_node;
 
+/* How ips_eval_program evaluates a tree.  AUTO (the default) = PER_OPERAND: one launch of a
+ * stand-alone predicate kernel per operand (a leaf, or two leaves on one column such as BETWEEN, in
+ * one pass) writing / AND-ing / OR-ing into a bitmap -- those kernels run at 70-80 % of the HBM
+ * roofline.  ONE_PASS: a conjunct / disjunct chain of up to four operands on REQUIRED FLE columns as
+ * one kernel that writes the bitmap once (other trees fall back to PER_OPERAND).  ONE_LAUNCH: the
+ * whole tree as one stack-machine kernel (REQUIRED columns only; 2-3x slower, for callers that
+ * must have a single launch).  Process-wide; every strategy produces identical bitmaps. */
+typedef enum { IPS_PROGRAM_AUTO = 0, IPS_PROGRAM_PER_OPERAND = 1, IPS_PROGRAM_ONE_PASS = 2,
+               IPS_PROGRAM_ONE_LAUNCH = 3 } ips_program_strategy;
+ips_status ips_set_program_strategy(int strategy);
+
 #define IPS_PROGRAM_MAX_NODES 32
 #define IPS_PROGRAM_MAX_COLS 8
 /* Trees that keep more than one bitmap alive (an OR of ANDs) and leaves on OPTIONAL columns (rank

@@ -65,8 +65,8 @@ def test_config2_2p28_rows_properties(capi, ips):
 
 
 def test_int64_dictionary_between_selectivity_sweep(capi, ips, O):
-    """configs[2]: int64 dictionary column (D = 4096, w = 12), BETWEEN = And(Ge lo, Le hi) and
-    And(Gt a, Lt b) at 1 / 10 / 50 / 100 % selectivity, fused program vs numpy."""
+    """configs[2]: int64 dictionary column (D = 4096, w = 12), BETWEEN = And(Ge lo, Le hi) at
+    1 / 10 / 50 / 100 % selectivity, fused program vs numpy (And(Gt a, Lt b): the tests below)."""
     n, D = 1 << 22, 4096
     rng = np.random.default_rng(3)
     dict_vals = np.sort(rng.choice(np.arange(-2 ** 40, 2 ** 40, 2 ** 20), D, replace=False)).astype(np.int64)
@@ -266,3 +266,117 @@ def test_config3_2p28_rows_dictionary_in_list(capi, ips):
         dd.close()
         del codes, enc
         torch.cuda.empty_cache()
+
+
+# ---- configs[0]/[1], the PLAIN twin (BASELINE.md 4 "1/2 PLAIN twin"): the same
+# splitmix64(0x5EED0001 + i) column as little-endian int32 slots (reinterpreted signed), LT with the
+# reference's reversed operands (parquet-common.h:208-217: bit = literal < x) and with SQL's ----
+def _bits(words_, n):
+    return np.unpackbits(np.ascontiguousarray(words_).view(np.uint8), bitorder="little")[:n].astype(bool)
+
+
+def test_config1_plain_int32_twin_1m_rows_bit_exact(capi, ips, O):
+    n = 1 << 20
+    vals = ips.synth.column_u32(ips.synth.SEED_HEADLINE, n, 32).view(np.int32)
+    c = np.int32(ips.synth.lt_constant(32))
+    page = O.plain_encode(vals, O.T_INT32)
+    d_page = capi.synth_u32(ips.synth.SEED_HEADLINE, n, 32)          # the generator twin, int32 slots
+    assert np.array_equal(d_page.cpu().numpy().view(np.uint8), page)
+    for sem, truth in ((O.SEM_REFERENCE, c < vals), (O.SEM_SQL, vals < c)):
+        ref = O.plain_pred(page, n, O.T_INT32, O.OP_LT, c, sem)      # parquet-common.h:208-217 / SQL order
+        assert np.array_equal(_bits(ref, n), truth), sem
+        assert np.array_equal(words(capi.plain_pred(d_page, n, capi.T_INT32, capi.OP_LT, c, sem)), ref), sem
+        bm, bv, cnt = capi.plain_scan(d_page, n, capi.T_INT32, capi.OP_LT, c, semantics=sem)
+        assert np.array_equal(words(bm), ref), sem
+        dense = capi.batches_compact(bv, cnt, n).cpu().numpy()
+        assert np.array_equal(dense, vals[truth]), sem                # ReadValue(skip) of the selected rows
+        bv2, cnt2 = capi.plain_select(d_page, n, capi.T_INT32, bm)
+        assert torch.equal(cnt2, cnt)
+        assert np.array_equal(capi.batches_compact(bv2, cnt2, n).cpu().numpy(), vals[truth]), sem
+    assert abs((vals < c).mean() - 0.60) < 0.005 and abs((c < vals).mean() - 0.40) < 0.005
+
+
+def test_config2_plain_int32_twin_2p28_rows(capi, ips):
+    """The PLAIN int32 twin at 2^28 rows: every bitmap bit and every selected slot against torch on
+    the raw values, both operand orders; predicate, fused scan and select."""
+    n = 1 << 28
+    c = int(ips.synth.lt_constant(32))
+    page = capi.synth_u32(ips.synth.SEED_HEADLINE, n, 32)            # int32 slots
+    for sem in (capi.SEM_REFERENCE, capi.SEM_SQL):
+        mask = (page > c) if sem == capi.SEM_REFERENCE else (page < c)
+        packed = _pack(mask)
+        assert torch.equal(capi.plain_pred(page, n, capi.T_INT32, capi.OP_LT, np.int32(c), sem), packed), sem
+        bm, bv, cnt = capi.plain_scan(page, n, capi.T_INT32, capi.OP_LT, np.int32(c), semantics=sem)
+        assert torch.equal(bm, packed), sem
+        exp = torch.masked_select(page, mask)
+        assert int(cnt.to(torch.int64).sum().item()) == exp.numel()
+        assert torch.equal(capi.batches_compact(bv, cnt, n), exp), sem
+        del bv
+        bv2, cnt2 = capi.plain_select(page, n, capi.T_INT32, bm)
+        assert torch.equal(cnt2, cnt)
+        assert torch.equal(capi.batches_compact(bv2, cnt2, n), exp), sem
+        del bv2, exp, mask, packed, bm
+        torch.cuda.empty_cache()
+
+
+def test_config2_2p28_rows_int64_and_gt_lt(capi, ips):
+    """configs[2]'s second form, And(Gt a, Lt b) (simple-predicates.h:145-153), at 2^28
+    rows on the PLAIN int64 column and on the D = 4096 dictionary, 1 / 10 / 50 / 100 %: every bitmap
+    bit against torch on the raw values; at 10 % also the selected values."""
+    n = 1 << 28
+    dev = torch.device("cuda")
+    lo32 = capi.synth_u32(0x5EED0003, n, 32).to(torch.int64) & 0xFFFFFFFF
+    plain = (capi.synth_u32(0x5EED1003, n, 8).to(torch.int64) << 32) | lo32      # values mod 2^40
+    del lo32
+    cols = [capi.plain_column(plain, capi.T_INT64)]
+    for sel in (0.01, 0.10, 0.50, 1.0):
+        a = int((0.5 - sel / 2) * (1 << 40)) - 1           # x > a AND x < b: the open interval
+        b = int((0.5 + sel / 2) * (1 << 40))
+        nodes = [capi.plain_leaf(0, capi.OP_GT, np.int64(a), capi.T_INT64),
+                 capi.plain_leaf(0, capi.OP_LT, np.int64(b), capi.T_INT64), capi.and_node()]
+        bm = capi.eval_program(nodes, cols, n)
+        mask = (plain > a) & (plain < b)
+        assert torch.equal(_pack(mask), bm), sel
+        assert abs(float(mask.sum().item()) / n - sel) < 0.002
+        # the two leaves one by one (ParquetPlainEncoder::Gt / Lt, SQL order) and their AND
+        g = capi.plain_pred(plain, n, capi.T_INT64, capi.OP_GT, np.int64(a))
+        l = capi.plain_pred(plain, n, capi.T_INT64, capi.OP_LT, np.int64(b))
+        assert torch.equal(capi.bitmap_and(g, l, n), bm), sel
+        if sel == 0.10:
+            bm2, bv, cnt = capi.plain_scan(plain, n, capi.T_INT64, capi.OP_GT, np.int64(a),
+                                           op2=capi.OP_LT, literal2=np.int64(b))
+            assert torch.equal(bm2, bm)
+            assert torch.equal(capi.batches_compact(bv, cnt, n), torch.masked_select(plain, mask))
+            del bv
+        del mask, bm, g, l
+    del plain, cols
+    torch.cuda.empty_cache()
+    D = 4096
+    rng = np.random.default_rng(3)
+    dict_vals = np.sort(rng.choice(np.arange(-2 ** 40, 2 ** 40, 2 ** 18), D, replace=False)).astype(np.int64)
+    codes = ((capi.synth_u32(0x5EED0003, n, 32).to(torch.int64) & 0xFFFFFFFF) % D).to(torch.int32)
+    enc = capi.fle_encode(codes, 12)
+    dd = capi.Dict(dict_vals.view(np.uint8), capi.T_INT64)
+    d_dict = torch.from_numpy(dict_vals).to(dev)
+    for sel in (0.01, 0.10, 0.50, 1.0):
+        ia, ib = int((0.5 - sel / 2) * (D - 1)), int((0.5 + sel / 2) * (D - 1))
+        a = dict_vals[ia] - (1 if sel == 1.0 else 0)       # 100 %: a below the first entry, b above the last
+        b = dict_vals[ib] + (1 if sel == 1.0 else 0)
+        mask = (codes > (ia if sel < 1.0 else -1)) & (codes < (ib if sel < 1.0 else D))
+        packed = _pack(mask)
+        g = dd.pred(enc, n, 12, capi.OP_GT, a)             # DictDecoder::Gt -> Ge(upper_bound), dict-encoding.h:473-483
+        l = dd.pred(enc, n, 12, capi.OP_LT, b)             # DictDecoder::Lt -> Lt(lower_bound), :485-495
+        assert torch.equal(capi.bitmap_and(g.clone(), l, n), packed), sel
+        ka, op_a, c_a = dd.translate(capi.OP_GT, a)
+        kb, op_b, c_b = dd.translate(capi.OP_LT, b)
+        if ka == capi.XL_FLE and kb == capi.XL_FLE:         # both leaves on the codes, one pass
+            nodes = [capi.leaf(0, op_a, c_a), capi.leaf(0, op_b, c_b), capi.and_node()]
+            assert torch.equal(capi.eval_program(nodes, [capi.fle_column(enc, 12)], n), packed), sel
+        else:
+            assert sel == 1.0
+        if sel == 0.10:
+            bv, cnt = dd.select(enc, n, 12, packed)
+            assert torch.equal(capi.batches_compact(bv, cnt, n), d_dict[torch.masked_select(codes, mask).to(torch.int64)])
+            del bv
+        del g, l, mask, packed
+    dd.close()

@@ -209,17 +209,15 @@ def test_nullable_dictionary_column(capi, O):
 
 
 @pytest.mark.parametrize("strategy", ["auto", "general", "one_pass"])
-def test_fused_program(capi, O, strategy, monkeypatch):
+def test_fused_program(capi, O, strategy, request):
     """EvalSimplePredicates over several columns vs numpy: BETWEEN = And(Ge, Le); And(Gt a, Lt b);
     Or; IN; PLAIN leaves (int32, int64, double).  'auto' lets ips_eval_program use the
     per-operand plan (stand-alone predicate kernels on a stack of bitmaps); 'general' forces the one-launch
     program kernel for every tree."""
-    if strategy == "one_pass":   # chains of <= 4 operands run as the one-pass kernel, the rest as planned
-        monkeypatch.setenv("IPS_PROGRAM_ONE_PASS", "1")
-    if strategy == "general":
-        monkeypatch.setenv("IPS_PROGRAM_NO_CHAIN", "1")
-    else:
-        monkeypatch.delenv("IPS_PROGRAM_NO_CHAIN", raising=False)
+    # 'one_pass': chains of <= 4 operands run as the one-pass kernel, the rest as planned
+    request.addfinalizer(lambda: capi.set_program_strategy(capi.PROGRAM_AUTO))
+    capi.set_program_strategy({"auto": capi.PROGRAM_AUTO, "general": capi.PROGRAM_ONE_LAUNCH,
+                               "one_pass": capi.PROGRAM_ONE_PASS}[strategy])
     rng = np.random.default_rng(23)
     for n in (1, 2047, 2049, 50021):
         c0 = rng.integers(0, 1 << 12, n).astype(np.uint32)
@@ -457,16 +455,14 @@ def test_dict_encode_on_gpu(capi, O, type_name):
 
 
 @pytest.mark.parametrize("strategy", ["auto", "general", "one_pass"])
-def test_random_predicate_trees(capi, O, strategy, monkeypatch):
+def test_random_predicate_trees(capi, O, strategy, request):
     """Random AND/OR trees (up to 12 leaves, any shape) over FLE and PLAIN columns against numpy:
     exercises the per-operand planner's bitmap stack (which bitmap ends up as the root, temporaries,
     same-column pairs, IN leaves) and the one-launch interpreter on the same programs."""
-    if strategy == "one_pass":   # chains of <= 4 operands run as the one-pass kernel, the rest as planned
-        monkeypatch.setenv("IPS_PROGRAM_ONE_PASS", "1")
-    if strategy == "general":
-        monkeypatch.setenv("IPS_PROGRAM_NO_CHAIN", "1")
-    else:
-        monkeypatch.delenv("IPS_PROGRAM_NO_CHAIN", raising=False)
+    # 'one_pass': chains of <= 4 operands run as the one-pass kernel, the rest as planned
+    request.addfinalizer(lambda: capi.set_program_strategy(capi.PROGRAM_AUTO))
+    capi.set_program_strategy({"auto": capi.PROGRAM_AUTO, "general": capi.PROGRAM_ONE_LAUNCH,
+                               "one_pass": capi.PROGRAM_ONE_PASS}[strategy])
     rng = np.random.default_rng(4242)
     n = 20000 + 37
     widths = (5, 12, 32)   # 32: the early-pruning kernel, also in its and-into / or-into modes

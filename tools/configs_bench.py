@@ -249,16 +249,14 @@ def main():
     exp2 = int((((cols_codes[0] >= 365) & (cols_codes[0] < 730) & (cols_codes[1] < 3))
                 | ((cols_codes[2] >= 40) & (cols_codes[1] >= 9))).sum().item())
     byts2 = (12 + 4 + 6 + 4) * 8 * Wq + 8 * Wq
-    for label, env in (("per-operand launches + one bitmap OR", None), ("one-launch program kernel", "1")):
-        if env:
-            os.environ["IPS_PROGRAM_NO_CHAIN"] = env
-        else:
-            os.environ.pop("IPS_PROGRAM_NO_CHAIN", None)
+    for label, strat in (("per-operand launches + one bitmap OR", capi.PROGRAM_AUTO),
+                         ("one-launch program kernel", capi.PROGRAM_ONE_LAUNCH)):
+        capi.set_program_strategy(strat)
         f2 = lambda: capi.eval_program(nodes2, cols, nq, bitmap=bm)
         tmin, tmed = timeit(f2)
         report(f"configs[4] (A and B and C) or (D and E), {label}", nq, byts2, tmin, tmed,
                capi.bitmap_count(bm, nq) == exp2)
-    os.environ.pop("IPS_PROGRAM_NO_CHAIN", None)
+    capi.set_program_strategy(capi.PROGRAM_AUTO)
     json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
                                      "configs_bench.json"), "w"), indent=1)
 
