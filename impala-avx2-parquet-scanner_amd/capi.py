@@ -47,6 +47,9 @@ SYMBOLS = [
     "ips_bitmap_and", "ips_bitmap_or", "ips_bitmap_fill", "ips_bitmap_count",
     "ips_expand_workspace_bytes", "ips_bitmap_expand",
     "ips_eval_program", "ips_set_program_strategy", "ips_synth_splitmix_u32",
+    "ips_chunk_open", "ips_chunk_close", "ips_chunk_num_rows", "ips_chunk_num_batches", "ips_chunk_num_pages",
+    "ips_chunk_program_workspace_bytes", "ips_eval_program_chunks", "ips_chunk_fle_scan", "ips_chunk_dict_scan",
+    "ips_chunk_plain_scan", "ips_chunk_select",
     "ips_comm_unique_id", "ips_comm_init", "ips_comm_destroy", "ips_allgather_bitmap",
     "ips_fle_scan_allgather", "ips_comm_join",
 ]
@@ -582,6 +585,110 @@ def eval_program(nodes, cols, n_rows, bitmap=None, device=None, stream=None, wor
             workspace = torch.empty(need, dtype=torch.uint8, device=device)
     _ck(lib().ips_eval_program(arr_n, len(nodes), arr_c, len(cols), C.c_int64(n_rows),
                                _ptr(bitmap), _ptr(workspace), _stream(stream)))
+    return bitmap[:_words(n_rows)]
+
+
+# ---- column chunks as lists of pages ----------------------------------------------------------
+class ChunkPage(C.Structure):
+    _fields_ = [("d_data", C.c_void_p), ("n_rows", C.c_int64), ("bit_width", C.c_int32),
+                ("reserved", C.c_int32), ("d_def_levels", C.c_void_p), ("n_data_rows", C.c_int64)]
+
+
+class Chunk:
+    """ips_chunk: pages = [(data tensor, n_rows, bit_width[, def_levels tensor, n_data_rows])];
+    the tensors are kept alive by the object."""
+
+    def __init__(self, pages, encoding=COL_FLE, type_=T_INT32, max_def_level=0):
+        self.keep = pages
+        arr = (ChunkPage * max(len(pages), 1))()
+        for i, pg in enumerate(pages):
+            arr[i].d_data = pg[0].data_ptr() if pg[0] is not None else 0
+            arr[i].n_rows = pg[1]
+            arr[i].bit_width = pg[2]
+            if len(pg) > 3:
+                arr[i].d_def_levels = pg[3].data_ptr()
+                arr[i].n_data_rows = pg[4]
+        self.h = C.c_void_p()
+        _ck(lib().ips_chunk_open(arr, len(pages), encoding, type_, max_def_level, C.byref(self.h)))
+        L = lib()
+        L.ips_chunk_num_rows.restype = C.c_int64
+        L.ips_chunk_num_batches.restype = C.c_int64
+        L.ips_chunk_num_rows.argtypes = [C.c_void_p]
+        L.ips_chunk_num_batches.argtypes = [C.c_void_p]
+        self.n_rows = int(L.ips_chunk_num_rows(self.h))
+        self.n_batches = int(L.ips_chunk_num_batches(self.h))
+        self.type = type_
+        self.device = next((pg[0].device for pg in pages if pg[0] is not None), torch.device("cuda"))
+
+    def close(self):
+        if self.h:
+            lib().ips_chunk_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def alloc_outputs(self, value_dtype=torch.int32):
+        dev = self.device
+        bitmap = torch.empty(max(_words(self.n_rows), 2), dtype=torch.int64, device=dev)
+        bvals = torch.empty(max(self.n_batches, 1) * BATCH_ROWS, dtype=value_dtype, device=dev)
+        counts = torch.empty(max(self.n_batches, 1), dtype=torch.int32, device=dev)
+        return bitmap, bvals, counts
+
+    def _ret(self, outs):
+        return outs[0][:_words(self.n_rows)], outs[1], outs[2][:self.n_batches]
+
+    def fle_scan(self, op, values, outputs=None, stream=None):
+        outs = outputs or self.alloc_outputs()
+        keep, cs, k = _consts(values)
+        _ck(lib().ips_chunk_fle_scan(self.h, op, cs, k, _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _stream(stream)))
+        return self._ret(outs)
+
+    def dict_scan(self, dict_, op, literals, outputs=None, stream=None):
+        outs = outputs or self.alloc_outputs(TORCH_SLOT[dict_.type])
+        keep, lp, k = dict_._lits(literals)
+        _ck(lib().ips_chunk_dict_scan(self.h, dict_.h, op, lp, k, _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]),
+                                      _stream(stream)))
+        return self._ret(outs)
+
+    def plain_scan(self, op, literals, op2=None, literal2=None, semantics=SEM_SQL, outputs=None, stream=None):
+        stride = int(lib().ips_plain_stride(self.type))
+        outs = outputs or self.alloc_outputs(torch.int32 if stride == 4 else torch.int64)
+        v = np.ascontiguousarray(np.atleast_1d(literals), dtype=NP_TYPES[self.type])
+        v2 = None if literal2 is None else np.ascontiguousarray(np.atleast_1d(literal2), dtype=NP_TYPES[self.type])
+        _ck(lib().ips_chunk_plain_scan(self.h, op, v.ctypes.data_as(C.c_void_p), len(v), 0 if op2 is None else op2,
+                                       None if v2 is None else v2.ctypes.data_as(C.c_void_p), semantics,
+                                       _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _stream(stream)))
+        return self._ret(outs)
+
+    def select(self, bitmap, dict_=None, outputs=None, stream=None):
+        outs = outputs or self.alloc_outputs(TORCH_SLOT[dict_.type] if dict_ else torch.int32)
+        _ck(lib().ips_chunk_select(self.h, dict_.h if dict_ else None, _ptr(bitmap), _ptr(outs[1]), _ptr(outs[2]),
+                                   _stream(stream)))
+        return outs[1], outs[2][:self.n_batches]
+
+    def compact(self, bvals, counts, stream=None):
+        return batches_compact(bvals, counts, self.n_batches * BATCH_ROWS, stream=stream)
+
+
+def eval_program_chunks(nodes, chunks, bitmap=None, workspace=None, stream=None):
+    """ips_eval_program_chunks: leaf.column indexes chunks."""
+    arr_n = (Node * len(nodes))(*nodes)
+    arr_c = (C.c_void_p * len(chunks))(*[c.h for c in chunks])
+    n_rows = chunks[0].n_rows
+    dev = chunks[0].device
+    L = lib()
+    L.ips_chunk_program_workspace_bytes.restype = C.c_size_t
+    need = int(L.ips_chunk_program_workspace_bytes(arr_n, len(nodes), arr_c, len(chunks)))
+    if workspace is None and need:
+        workspace = torch.empty(need + 16, dtype=torch.uint8, device=dev)
+    if bitmap is None:
+        bitmap = torch.empty(max(_words(n_rows), 2), dtype=torch.int64, device=dev)
+    _ck(L.ips_eval_program_chunks(arr_n, len(nodes), arr_c, len(chunks), _ptr(bitmap), _ptr(workspace),
+                                  _stream(stream)))
     return bitmap[:_words(n_rows)]
 
 

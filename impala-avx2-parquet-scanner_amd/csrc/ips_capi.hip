@@ -218,9 +218,7 @@ static bool check_fle_common(const void* d_enc, int64_t n_rows, int bw, const ch
 
 // Outcome of comparing against constants that do not fit in bw bits (the
 // reference is inconsistent there; the build defines it by the unsigned SQL meaning).
-enum ConstKind { kEvaluate = 0, kAllFalse = 1, kAllTrue = 2 };
-
-static ips_status build_pred_args(int bw, ips_op op, const uint64_t* consts, int n_consts,
+ips_status build_pred_args(int bw, ips_op op, const uint64_t* consts, int n_consts,
                                   PredArgs* args, ConstKind* kind, const char* fn) {
   if (op < IPS_OP_EQ || op > IPS_OP_IN) { set_error("%s: bad op %d", fn, (int)op); return IPS_ERR_INVALID_ARG; }
   if (consts == nullptr || n_consts < 1) { set_error("%s: no constants", fn); return IPS_ERR_INVALID_ARG; }
@@ -574,14 +572,6 @@ size_t ips_assemble_workspace_bytes(int64_t n_rows, int n_optional_cols) {
 // ---- dictionary -----------------------------------------------------------------------------
 }  // extern "C"
 
-struct ips_dict {
-  ips_type type;
-  int64_t n;
-  int elem;                     // sizeof(T)
-  int slot;                     // PLAIN slot / device entry bytes: 4 or 8
-  std::vector<uint8_t> host;    // n elements of sizeof(T), ascending
-  void* d_entries;              // n entries of 'slot' bytes (int8/int16 sign-extended to int32)
-};
 
 namespace ips {
 static int type_elem(ips_type t) {
@@ -653,8 +643,8 @@ static void translate_t(const ips_dict* d, ips_op op, const void* literals, int 
   }
 }
 
-static ips_status translate(const ips_dict* d, ips_op op, const void* literals, int n_literals,
-                            ips_xl_kind* kind, ips_op* fle_op, uint64_t* codes, int* n_codes) {
+ips_status translate(const ips_dict* d, ips_op op, const void* literals, int n_literals,
+                     ips_xl_kind* kind, ips_op* fle_op, uint64_t* codes, int* n_codes) {
   switch (d->type) {
     case IPS_T_INT8: translate_t<int8_t>(d, op, literals, n_literals, kind, fle_op, codes, n_codes); break;
     case IPS_T_INT16: translate_t<int16_t>(d, op, literals, n_literals, kind, fle_op, codes, n_codes); break;
@@ -666,8 +656,8 @@ static ips_status translate(const ips_dict* d, ips_op op, const void* literals, 
   return IPS_OK;
 }
 
-static ips_status check_dict_call(const ips_dict* dict, ips_op op, const void* literals,
-                                  int n_literals, const char* fn) {
+ips_status check_dict_call(const ips_dict* dict, ips_op op, const void* literals,
+                           int n_literals, const char* fn) {
   IPS_REQUIRE(dict != nullptr, "%s: NULL dictionary", fn);
   IPS_REQUIRE(op >= IPS_OP_EQ && op <= IPS_OP_IN, "%s: bad op %d", fn, (int)op);
   IPS_REQUIRE(literals != nullptr && n_literals >= 1, "%s: no literals", fn);

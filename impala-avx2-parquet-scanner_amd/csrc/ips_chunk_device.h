@@ -1,0 +1,178 @@
+// ips_chunk_device.h -- a column chunk as a LIST OF PAGES on the device, and how kernels that
+// work page by page write into (and read from) bitmaps over the chunk's row space.
+//
+// The scanner holds a column chunk as data pages whose row counts are whatever the writer chose
+// (ReadDataPage / InitDataPage per page, hdfs-parquet-scanner.cc:730-924); pages of different
+// columns end at different rows, and EvalSimplePredicates cuts its batches at every column's page
+// end (hdfs-parquet-scanner.cc:1837-1855).  Here every page is evaluated in ITS OWN block geometry
+// (FLE blocks of 64 rows start at the page's first row; blockIdx.y = page, one launch per run of
+// pages of one bit width) and the result is written at the page's row offset of the chunk-wide
+// bitmap.  A lane's 32 rows then straddle two bitmap dwords whenever row0 % 32 != 0:
+//   * inside the wave the neighbour's bits arrive by one DPP wave shift, and every dword all of
+//     whose 32 bits come from this wave is an ordinary store / read-modify-write;
+//   * a dword shared with the previous or next sub-tile, or with the neighbouring PAGE, is merged
+//     with atomics on exactly the bits this wave owns -- clear-then-set (store), and-with-mask
+//     (AND into) or or (OR into) -- so the result does not depend on the order in which the
+//     sharers arrive and needs no zero-initialised bitmap;
+//   * the last page also owns the bits behind the chunk's last row up to the end of the bitmap's
+//     last 64-bit word (they are zero, as in every bitmap of this library).
+// Pages that start on a multiple of 32 rows and hold a multiple of 32 rows take the same stores as
+// the single-buffer kernels.
+#pragma once
+#include "ips_device.h"
+
+namespace ips {
+
+// One page as the kernels see it: 64 bytes, wave-uniform, read with scalar loads by blockIdx.y.
+struct ChunkPage {
+  const uint64_t* data;    // FLE blocks (codes / values; OPTIONAL: of the non-NULL rows) or PLAIN slots
+  const uint64_t* levels;  // OPTIONAL: FLE blocks (width 1) of the page's definition levels, else NULL
+  int64_t n_rows;          // rows of the page, NULLs included
+  int64_t n_data;          // rows 'data' holds (REQUIRED: n_rows)
+  int64_t row0;            // first row of the page within the chunk
+  uint32_t batch0;         // 2048-row sub-tiles of all earlier pages: the page's first batch slot
+  uint32_t flags;          // bit 0: last page of the chunk
+  uint32_t rank0;          // OPTIONAL: first entry of the page's tile counts in the rank workspace
+  uint32_t reserved;
+};
+static_assert(sizeof(ChunkPage) == 56 || sizeof(ChunkPage) == 64, "page descriptor layout");
+constexpr uint32_t kPageLast = 1u;
+
+// Where a page's lane dwords go inside the chunk-wide bitmap (all wave-uniform).
+struct BitmapWindow {
+  uint32_t* base;        // dword that holds the page's first row
+  uint32_t shift;        // row0 % 32
+  uint32_t own_tail;     // last page: owns the bits behind the chunk's last row (see above)
+  int64_t n_rows;        // rows of the page
+  int64_t tail_dword;    // last page: page-relative index of the dword that holds the chunk's last row
+  uint32_t tail_mask;    //            its bits behind that row
+  uint32_t tail_extra;   //            1: the bitmap's last word has one more dword behind it
+};
+
+__device__ __forceinline__ BitmapWindow bitmap_window(uint32_t* bitmap32, const ChunkPage& pg, int64_t chunk_rows) {
+  BitmapWindow w;
+  w.base = bitmap32 + (pg.row0 >> 5);
+  w.shift = (uint32_t)(pg.row0 & 31);
+  w.own_tail = pg.flags & kPageLast;
+  w.n_rows = pg.n_rows;
+  const int64_t last = chunk_rows - 1;  // (a chunk with pages has rows)
+  w.tail_dword = (last >> 5) - (pg.row0 >> 5);
+  const uint32_t b = (uint32_t)(last & 31);
+  w.tail_mask = b == 31u ? 0u : ~((2u << b) - 1u);
+  w.tail_extra = ((last >> 5) & 1) == 0 ? 1u : 0u;  // an even dword index is followed by the word's high half
+  return w;
+}
+
+// one dword of the chunk-wide bitmap: 'mask' = the bits this lane owns, 'val' its values there
+// (val & ~mask == 0).  combine: 0 store, 1 AND into, 2 OR into.
+__device__ __forceinline__ void window_put(uint32_t* p, uint32_t val, uint32_t mask, int combine) {
+  if (mask == 0u) return;
+  if (mask == ~0u) {
+    if (combine == 1) val &= *p;
+    else if (combine == 2) val |= *p;
+    IPS_BITMAP_STORE(p, val);
+    return;
+  }
+  if (combine == 0) {
+    atomicAnd(p, ~mask);
+    if (val) atomicOr(p, val);
+  } else if (combine == 1) {
+    atomicAnd(p, val | ~mask);
+  } else if (val) {
+    atomicOr(p, val);
+  }
+}
+
+// The wave holds a run of consecutive page-relative bitmap dwords, lane l the dword d = d0 + l: 'bm'
+// (bit j <-> row 32 d + j of the page, rows beyond the page already cleared).  Lanes that hold no
+// dword of their own pass active = false (they still deliver the high part of the lane before
+// them).  Every lane of the wave calls it.  combine: 0 store, 1 AND into, 2 OR into.
+__device__ __forceinline__ void window_emit(const BitmapWindow& w, int64_t d, bool active, uint32_t bm, int combine) {
+  const int64_t valid = w.n_rows - d * 32;
+  const uint32_t vm = !active ? 0u : valid >= 32 ? ~0u : valid <= 0 ? 0u : ((1u << valid) - 1u);
+  bm &= vm;
+  uint32_t val = bm, mask = vm;
+  if (w.shift != 0u) {  // wave-uniform
+    const uint32_t s = w.shift, r = 32u - s;
+    const uint32_t up_bm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bm, 0x138, 0xF, 0xF, true);  // wave_shr:1
+    const uint32_t up_vm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vm, 0x138, 0xF, 0xF, true);  // (lane 0: 0)
+    val = (bm << s) | (up_bm >> r);
+    mask = (vm << s) | (up_vm >> r);
+  }
+  const bool tail = w.own_tail && d == w.tail_dword && mask != 0u;  // zeros behind the chunk's last row
+  if (tail) mask |= w.tail_mask;
+  window_put(w.base + d, val, mask, combine);
+  if (tail && w.tail_extra && combine != 2) IPS_BITMAP_STORE(w.base + d + 1, 0u);
+  if (w.shift != 0u && (threadIdx.x & (kWave - 1)) == kWave - 1 && vm != 0u) {  // the last lane's high part: dword d + 1
+    const uint32_t v2 = bm >> (32u - w.shift);
+    uint32_t m2 = vm >> (32u - w.shift);
+    const bool tail2 = w.own_tail && d + 1 == w.tail_dword && m2 != 0u;
+    if (tail2) m2 |= w.tail_mask;
+    window_put(w.base + d + 1, v2, m2, combine);
+    if (tail2 && w.tail_extra && combine != 2) IPS_BITMAP_STORE(w.base + d + 2, 0u);
+  }
+}
+
+// The same for a wave whose lanes hold FOUR consecutive dwords each (two 64-bit words per lane, the
+// nullable leaf): in[k] = page-relative dword d0 + k, lane l + 1 continues where lane l ends.
+__device__ __forceinline__ void window_emit_quad(const BitmapWindow& w, int64_t d0, const uint32_t (&in)[4], int combine) {
+  uint32_t bm[4], vm[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t valid = w.n_rows - (d0 + k) * 32;
+    vm[k] = valid >= 32 ? ~0u : valid <= 0 ? 0u : ((1u << valid) - 1u);
+    bm[k] = in[k] & vm[k];
+  }
+  const uint32_t s = w.shift, r = 32u - s;
+  uint32_t pb = 0u, pv = 0u;
+  if (s != 0u) {  // wave-uniform
+    pb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bm[3], 0x138, 0xF, 0xF, true) >> r;  // wave_shr:1 (lane 0: 0)
+    pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vm[3], 0x138, 0xF, 0xF, true) >> r;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t val = (bm[k] << s) | pb;
+    uint32_t mask = (vm[k] << s) | pv;
+    const bool tail = w.own_tail && d0 + k == w.tail_dword && mask != 0u;
+    if (tail) mask |= w.tail_mask;
+    window_put(w.base + d0 + k, val, mask, combine);
+    if (tail && w.tail_extra && combine != 2) IPS_BITMAP_STORE(w.base + d0 + k + 1, 0u);
+    pb = s != 0u ? bm[k] >> r : 0u;
+    pv = s != 0u ? vm[k] >> r : 0u;
+  }
+  if (s != 0u && (threadIdx.x & (kWave - 1)) == kWave - 1 && pv != 0u) {  // the last lane's high part
+    uint32_t m2 = pv;
+    const bool tail2 = w.own_tail && d0 + 4 == w.tail_dword;
+    if (tail2) m2 |= w.tail_mask;
+    window_put(w.base + d0 + 4, pb, m2, combine);
+    if (tail2 && w.tail_extra && combine != 2) IPS_BITMAP_STORE(w.base + d0 + 5, 0u);
+  }
+}
+
+// The other direction: this lane's dword of a selection over the chunk's rows (bit j <-> row
+// 32 * lane + j of sub-tile 'tile' of the page; rows beyond the page cleared).  'words32' dwords
+// exist in the bitmap.
+__device__ __forceinline__ uint32_t window_fetch(const uint32_t* __restrict__ bitmap32, int64_t total_dwords,
+                                                 const ChunkPage& pg, int64_t tile, int lane) {
+  const int64_t d = tile * 64 + lane;
+  const int64_t g = (pg.row0 >> 5) + d;
+  const uint32_t s = (uint32_t)(pg.row0 & 31);
+  const int64_t valid = pg.n_rows - d * 32;
+  if (__builtin_amdgcn_ballot_w64(valid > 0) == 0ull) return 0u;  // wave-uniform: nothing of the page here
+  // (a dword right behind the page's last row of this lane may still hold rows of the lane before it)
+  uint32_t lo = (valid > -32 && g < total_dwords) ? bitmap32[g] : 0u;
+  uint32_t x = lo;
+  if (s != 0u) {  // wave-uniform
+    uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x130, 0xF, 0xF, true);  // wave_shl:1: lane i <- lane i + 1
+    if (lane == kWave - 1) hi = (valid > 0 && g + 1 < total_dwords) ? bitmap32[g + 1] : 0u;  // (the last lane has no neighbour)
+    x = (lo >> s) | (hi << (32u - s));
+  }
+  return valid >= 32 ? x : valid <= 0 ? 0u : (x & ((1u << valid) - 1u));
+}
+
+// the page a workgroup works on (blockIdx.y of a paged launch)
+__device__ __forceinline__ ChunkPage load_page(const ChunkPage* __restrict__ pages) {
+  return pages[blockIdx.y];
+}
+
+}  // namespace ips

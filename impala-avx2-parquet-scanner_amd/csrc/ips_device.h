@@ -27,6 +27,9 @@ constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = kWave * kWavesPerBlock;
 
+// what a fused scan kernel evaluates (ips_fle_kernels.h)
+enum ScanMode { kScanPredicate = 0, kScanGivenBitmap = 1, kScanInList = 2, kScanInTable = 3 };
+
 // Predicate parameters travel in the kernarg segment: wave-uniform, read with scalar loads.
 struct PredArgs {
   int32_t op;        // ips_op

@@ -7,6 +7,7 @@
 #pragma once
 #include "ips_device.h"
 #include "ips_rank_device.h"
+#include "ips_chunk_device.h"
 
 // (nt loads in decode / encode pay once their output streams are nt stores as well, -3...-4 %;
 // with plain stores they measured 4 % slower: IPS_DECODE_NT_LOADS / IPS_ENCODE_NT_LOADS, ips_knobs.h)
@@ -14,7 +15,6 @@
 namespace ips {
 
 
-enum ScanMode { kScanPredicate = 0, kScanGivenBitmap = 1, kScanInList = 2, kScanInTable = 3 };
 
 // Dictionary gather applied while values leave LDS: G = 0 none (store the code / raw value),
 // 4 / 8 = bytes per dictionary entry.
@@ -121,14 +121,24 @@ struct ScanLds {
                                    : W <= IPS_SCAN_SMALL_LDS_MAX_W ? 8 : 5;
 };
 
+// A page of a column chunk inside the chunk's row space (PAGED kernels: ips_chunk_device.h): where
+// its bitmap dwords go, where a given selection is read from.
+struct PageCtx {
+  BitmapWindow win;
+  ChunkPage page;
+  int64_t total_dwords;  // dwords of the chunk-wide bitmap
+};
+
 // first_tile / stride: the sub-tiles this wave takes (tile = first_tile, first_tile + stride, ...)
-template <int W, int MODE, int G>
+// PAGED: enc / n_rows are one page of a chunk; the bitmap (written, or given) is the chunk's, the
+// batch outputs start at the page's first batch slot.
+template <int W, int MODE, int G, bool PAGED = false>
 __device__ __forceinline__ void fle_scan_body(
     const uint64_t* __restrict__ enc, int64_t n_rows, const PredArgs& args,
     uint32_t* __restrict__ bitmap32, const uint32_t* __restrict__ given_bitmap32,
     typename GatherT<G>::type* __restrict__ batch_values, uint32_t* __restrict__ batch_counts,
     const typename GatherT<G>::type* __restrict__ dict, uint32_t dict_entries,
-    int32_t* __restrict__ bad_index, int64_t first_tile, int64_t stride) {
+    int32_t* __restrict__ bad_index, int64_t first_tile, int64_t stride, const PageCtx* pc = nullptr) {
   constexpr int kWB = ScanLds<W, MODE>::kWaveBytes;
   constexpr bool kSmallLds = ScanLds<W, MODE>::kSmall;
   constexpr bool kWindowed = ScanLds<W, MODE>::kWindowed;
@@ -163,8 +173,21 @@ __device__ __forceinline__ void fle_scan_body(
 
   // given bitmap: this lane's dword of the sub-tile, and which blocks hold a selected row
   auto given_dword = [&](int64_t t) -> uint32_t {
-    const int64_t gd = t * 64 + lane;
-    return (t < tiles && gd < bm_dwords) ? given_bitmap32[gd] : 0u;
+    if constexpr (PAGED) {
+      return t < tiles ? window_fetch(given_bitmap32, pc->total_dwords, pc->page, t, lane) : 0u;
+    } else {
+      const int64_t gd = t * 64 + lane;
+      return (t < tiles && gd < bm_dwords) ? given_bitmap32[gd] : 0u;
+    }
+  };
+  // this lane's bitmap dword of sub-tile t (rows beyond n_rows cleared) -> the bitmap
+  auto put_dword = [&](int64_t t, uint32_t dword) {
+    if constexpr (PAGED) {
+      window_emit(pc->win, t * 64 + lane, true, dword, 0);
+    } else {
+      const int64_t dd = t * 64 + lane;
+      if (dd < bm_dwords) IPS_BITMAP_STORE(bitmap32 + dd, dword);
+    }
   };
   auto needed_blocks = [&](uint32_t g) -> uint64_t {
     const uint64_t any = __builtin_amdgcn_ballot_w64(g != 0u);  // bit l <-> half-block of lane l
@@ -205,11 +228,11 @@ __device__ __forceinline__ void fle_scan_body(
     }
     wave_lds_fence();
 
-    const int64_t d = tile * 64 + lane;
+    [[maybe_unused]] const int64_t d = tile * 64 + lane;
     uint32_t bm;
     if (MODE == kScanInList && W > 16) {  // wide IN: K passes over the planes in LDS, before they enter VGPRs
       bm = finish_bitmap_dword(pred_from_lds(lds32, W, lane, args), tile, lane, n_rows);
-      if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, bm);
+      put_dword(tile, bm);
     }
     uint32_t p[W];
     planes_from_lds<W>(lds32, lane, p);
@@ -217,20 +240,20 @@ __device__ __forceinline__ void fle_scan_body(
     if (kInTable) {  // long list: decode first, one set lookup per value
       planes_to_values<W>(p, v);
       bm = finish_bitmap_dword(bitrev32(in_table_lookup(in_table, v)), tile, lane, n_rows);
-      if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, bm);
+      put_dword(tile, bm);
     }
     if (MODE == kScanInList && W <= 16) {
       bm = finish_bitmap_dword(pred_in_from_regs<W>(p, args.consts, args.n_consts), tile, lane, n_rows);
-      if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, bm);
+      put_dword(tile, bm);
     }
     if (MODE == kScanPredicate) {
       const uint32_t sel = pred_from_regs<W>(p, args);
-      if ((tile + 1) * kRowsPerTile <= n_rows) {  // wave-uniform: every row of the sub-tile exists
+      if (!PAGED && (tile + 1) * kRowsPerTile <= n_rows) {  // wave-uniform: every row of the sub-tile exists
         bm = bitrev32(sel);
         IPS_BITMAP_STORE(bitmap32 + d, bm);
       } else {
         bm = finish_bitmap_dword(sel, tile, lane, n_rows);
-        if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, bm);
+        put_dword(tile, bm);
       }
     } else if (MODE == kScanGivenBitmap) {
       bm = bitrev32(given_cur);  // finish_bitmap_dword reverses back; only the row mask is wanted
@@ -538,6 +561,27 @@ __global__ __launch_bounds__(kThreads, (ScanLds<W, kScanPredicate>::kMinWaves)) 
 #endif
 }
 
+// The fused scan (and, MODE = kScanGivenBitmap, the late materialisation against a selection) over
+// the pages of a column chunk: blockIdx.y = page, the bitmap is the chunk's, batch slot
+// page.batch0 + sub-tile holds the sub-tile's selected values (the chunk's batch list is the
+// concatenation of the pages' batches: a page's last batch is partial).
+template <int W, int MODE, int G>
+__global__ __launch_bounds__(kThreads, (ScanLds<W, MODE>::kMinWaves)) void fle_scan_chunk_kernel(
+    const ChunkPage* __restrict__ pages, int64_t chunk_rows, PredArgs args, uint32_t* __restrict__ bitmap32,
+    const uint32_t* __restrict__ given_bitmap32, typename GatherT<G>::type* __restrict__ batch_values,
+    uint32_t* __restrict__ batch_counts, const typename GatherT<G>::type* __restrict__ dict,
+    uint32_t dict_entries, int32_t* __restrict__ bad_index) {
+  PageCtx pc;
+  pc.page = pages[blockIdx.y];
+  pc.win = bitmap_window(bitmap32, pc.page, chunk_rows);
+  pc.total_dwords = bitmap_dwords(chunk_rows);
+  fle_scan_body<W, MODE, G, true>(pc.page.data, pc.page.n_data, args, nullptr, given_bitmap32,
+                                  batch_values + (int64_t)pc.page.batch0 * kRowsPerTile,
+                                  batch_counts + pc.page.batch0, dict, dict_entries, bad_index,
+                                  (int64_t)blockIdx.x * kWavesPerBlock + wave_id(),
+                                  (int64_t)gridDim.x * kWavesPerBlock, &pc);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Predicate only: FleDecoder::Eq/Lt/Le/Gt/Ge/In on the encoded planes (fle-encoding.h:7962-8313).
 // Nothing is decoded: per 64 rows the wave reads W words and writes one.  args.combine and-s /
@@ -547,13 +591,12 @@ __global__ __launch_bounds__(kThreads, (ScanLds<W, kScanPredicate>::kMinWaves)) 
 // ---------------------------------------------------------------------------------------------
 enum PredKind { kPredSingle = 0, kPredPair = 1, kPredInList = 2, kPredInTable = 3 };
 
-template <int W, int KIND>
-__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_w_kernel(
-    const uint64_t* __restrict__ enc, int64_t n_rows, PredArgs args,
-    uint32_t* __restrict__ bitmap32) {
+template <int W, int KIND, bool PAGED>
+__device__ __forceinline__ void fle_pred_body(const uint64_t* __restrict__ enc, int64_t n_rows, const PredArgs& args,
+                                              uint32_t* __restrict__ bitmap32, const BitmapWindow* win) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * plane_tile_bytes(W) / 4];
   constexpr int L = (16 * W + kWave - 1) / kWave;
-  if ((int)blockIdx.x < args.aux_blocks) {  // counting workgroups of a nullable leaf
+  if (!PAGED && (int)blockIdx.x < args.aux_blocks) {  // counting workgroups of a nullable leaf
     rank_aux_counts(args);
     return;
   }
@@ -601,7 +644,9 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_w_ker
     }
     uint32_t bm = finish_bitmap_dword(sel, tile, lane, n_rows);
     const int64_t d = tile * 64 + lane;
-    if (d < bm_dwords) {
+    if constexpr (PAGED) {
+      window_emit(*win, d, true, bm, args.combine);
+    } else if (d < bm_dwords) {
       if (args.combine == 1) bm &= bitmap32[d];
       else if (args.combine == 2) bm |= bitmap32[d];
       IPS_BITMAP_STORE(bitmap32 + d, bm);
@@ -609,6 +654,23 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_w_ker
     wave_lds_fence();  // LDS region is reused by the next sub-tile
     tile = next;
   }
+}
+
+template <int W, int KIND>
+__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_w_kernel(
+    const uint64_t* __restrict__ enc, int64_t n_rows, PredArgs args,
+    uint32_t* __restrict__ bitmap32) {
+  fle_pred_body<W, KIND, false>(enc, n_rows, args, bitmap32, nullptr);
+}
+
+// The same over the pages of a column chunk (blockIdx.y = page; ips_chunk_device.h): every page in
+// its own block geometry, the result at the page's row offset of the chunk-wide bitmap.
+template <int W, int KIND>
+__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_pages_kernel(
+    const ChunkPage* __restrict__ pages, int64_t chunk_rows, PredArgs args, uint32_t* __restrict__ bitmap32) {
+  const ChunkPage pg = pages[blockIdx.y];
+  const BitmapWindow win = bitmap_window(bitmap32, pg, chunk_rows);
+  fle_pred_body<W, KIND, true>(pg.data, pg.n_data, args, nullptr, &win);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -628,9 +690,14 @@ constexpr int kLeafSubTiles = (63 + kExpWordsPerWave * 64 + 2047) / 2048;  // 9
 constexpr int kLeafSegDwords = kLeafSubTiles * 64;
 static_assert(kThreads == kRankThreads, "a leaf workgroup is an expand workgroup");
 
-template <int W, int KIND>
-__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_leaf_kernel(
-    const uint64_t* __restrict__ enc, int64_t n_sub, PredArgs args, u64* __restrict__ out) {
+// PAGED: the same per page of a column chunk (blockIdx.y = page): the page's levels, data blocks and
+// tile counts (args.aux_counts + page.rank0), the result deposited at the page's row offset of the
+// chunk-wide bitmap 'out'.
+template <int W, int KIND, bool PAGED>
+__device__ __forceinline__ void fle_leaf_body(const uint64_t* __restrict__ enc, int64_t n_sub, const PredArgs& args,
+                                              u64* __restrict__ out, const BitmapWindow* win,
+                                              const u64* __restrict__ root, int root_kind, int64_t n_rows,
+                                              const uint32_t* __restrict__ tile_counts) {
   constexpr bool kInTable = KIND == kPredInTable && InTable<W>::kUse;
   static_assert(KIND != kPredInTable || InTable<W>::kUse, "the membership table holds codes of <= 16 bits");
   __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * plane_tile_bytes(W) / 4];
@@ -647,15 +714,12 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_leaf_kerne
   uint32_t* seg = seg_all[wave];
   lut[threadIdx.x] = (uint8_t)deposit_lut_entry(threadIdx.x);
 
-  const u64* __restrict__ root = reinterpret_cast<const u64*>(args.aux_root);
-  const uint32_t* __restrict__ tile_counts = args.aux_counts;
-  const int64_t n_rows = args.aux_rows;
   const int64_t n_words = (n_rows + 63) / 64;
   const int64_t tiles = (n_words + kRankWordsPerTile - 1) / kRankWordsPerTile;
   const int64_t first = (int64_t)blockIdx.x * kExpWordsPerBlock + wave * kExpWordsPerWave;
   const bool whole = (first + kExpWordsPerWave) * 64 <= n_rows;  // wave-uniform
   u64 m[kExpRounds][2];
-  if (args.aux_kind == kRootLevels1) {
+  if (root_kind == kRootLevels1) {
     if (whole) load_root_whole<kRootLevels1, kExpRounds>(root, first, lane, m);
     else load_root<kRootLevels1, kExpRounds>(root, first, n_words, n_rows, lane, m);
   } else {
@@ -852,6 +916,15 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_leaf_kerne
       res[e] = (u64)deposit32(lo, mlo, lut) | ((u64)deposit32(src_hi, mhi, lut) << 32);
       rel += (uint32_t)__builtin_popcountll(m[r2][e]);
     }
+    if constexpr (PAGED) {
+      // whole words on a 16-byte boundary of the chunk's bitmap take the stores below; everything
+      // else goes dword by dword through the window (shifted, shared dwords merged atomically)
+      if (!(whole && win->shift == 0u && (reinterpret_cast<uintptr_t>(win->base) & 15u) == 0u)) {
+        const uint32_t in[4] = {(uint32_t)res[0], (uint32_t)(res[0] >> 32), (uint32_t)res[1], (uint32_t)(res[1] >> 32)};
+        window_emit_quad(*win, 2 * w0, in, args.combine);
+        continue;
+      }
+    }
     if (w0 + 1 < n_words) {
       u32x4* dst = reinterpret_cast<u32x4*>(out + w0);
       if (args.combine != 0) {  // wave-uniform
@@ -867,6 +940,24 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_leaf_kerne
       out[w0] = res[0];
     }
   }
+}
+
+template <int W, int KIND>
+__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_leaf_kernel(
+    const uint64_t* __restrict__ enc, int64_t n_sub, PredArgs args, u64* __restrict__ out) {
+  fle_leaf_body<W, KIND, false>(enc, n_sub, args, out, nullptr, reinterpret_cast<const u64*>(args.aux_root),
+                                args.aux_kind, args.aux_rows, args.aux_counts);
+}
+
+template <int W, int KIND>
+__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_leaf_pages_kernel(
+    const ChunkPage* __restrict__ pages, int64_t chunk_rows, PredArgs args, uint32_t* __restrict__ bitmap32) {
+  const ChunkPage pg = pages[blockIdx.y];
+  if ((int64_t)blockIdx.x * kExpWordsPerBlock * 64 >= pg.n_rows) return;  // (the grid is sized for the largest page)
+  const BitmapWindow win = bitmap_window(bitmap32, pg, chunk_rows);
+  fle_leaf_body<W, KIND, true>(pg.data, pg.n_data, args, reinterpret_cast<u64*>(win.base), &win,
+                               reinterpret_cast<const u64*>(pg.levels), kRootLevels1, pg.n_rows,
+                               args.aux_counts + pg.rank0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1169,13 +1260,13 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_select_nul
 // ---------------------------------------------------------------------------------------------
 // PAIR: two comparisons on the column in the same pass (BETWEEN): a row needs the low planes if it
 // is still equal to either constant.
-template <int W, bool PAIR>  // W = 32 only
-__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_early_kernel(
-    const uint64_t* __restrict__ enc, int64_t n_rows, PredArgs args,
-    uint32_t* __restrict__ bitmap32) {
+template <int W, bool PAIR, bool PAGED>  // W = 32 only
+__device__ __forceinline__ void fle_pred32_early_body(const uint64_t* __restrict__ enc, int64_t n_rows,
+                                                      const PredArgs& args, uint32_t* __restrict__ bitmap32,
+                                                      const BitmapWindow* win) {
   static_assert(W == 32, "two 128-byte lines per block");
   __shared__ __attribute__((aligned(16))) uint32_t lds_all[kWavesPerBlock * plane_tile_bytes(W) / 4];
-  if ((int)blockIdx.x < args.aux_blocks) {  // counting workgroups of a nullable leaf
+  if (!PAGED && (int)blockIdx.x < args.aux_blocks) {  // counting workgroups of a nullable leaf
     rank_aux_counts(args);
     return;
   }
@@ -1270,7 +1361,9 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_ear
     }
     uint32_t bm = finish_bitmap_dword(sel, tile, lane, n_rows);
     const int64_t d = tile * 64 + lane;
-    if (d < bm_dwords) {
+    if constexpr (PAGED) {
+      window_emit(*win, d, true, bm, args.combine);
+    } else if (d < bm_dwords) {
       if (args.combine == 1) bm &= bitmap32[d];
       else if (args.combine == 2) bm |= bitmap32[d];
       IPS_BITMAP_STORE(bitmap32 + d, bm);
@@ -1278,6 +1371,20 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_ear
     wave_lds_fence();  // LDS region is reused by the next sub-tile
     tile = next;
   }
+}
+
+template <int W, bool PAIR>
+__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_early_kernel(
+    const uint64_t* __restrict__ enc, int64_t n_rows, PredArgs args, uint32_t* __restrict__ bitmap32) {
+  fle_pred32_early_body<W, PAIR, false>(enc, n_rows, args, bitmap32, nullptr);
+}
+
+template <int W, bool PAIR>
+__global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_early_pages_kernel(
+    const ChunkPage* __restrict__ pages, int64_t chunk_rows, PredArgs args, uint32_t* __restrict__ bitmap32) {
+  const ChunkPage pg = pages[blockIdx.y];
+  const BitmapWindow win = bitmap_window(bitmap32, pg, chunk_rows);
+  fle_pred32_early_body<W, PAIR, true>(pg.data, pg.n_data, args, nullptr, &win);
 }
 
 // ---------------------------------------------------------------------------------------------

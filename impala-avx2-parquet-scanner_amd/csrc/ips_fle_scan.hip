@@ -3,7 +3,7 @@
 #include <stdlib.h>
 
 #include "ips_fle_kernels.h"
-#include "ips_host.h"
+#include "ips_chunk_host.h"
 
 #ifndef IPS_WLO
 #error "compile with -DIPS_WLO=.. -DIPS_PART=.."
@@ -245,6 +245,173 @@ ips_status IPS_CAT(launch_fle_selnull_part_, IPS_PART)(int w, int gather, const 
                                                        uint32_t dict_entries, int64_t* n_values, hipStream_t s) {
 #define IPS_CASE(N) \
   case IPS_WLO + N: return launch_selnull_w<IPS_WLO + N>(gather, enc, n_data, a, dense, dict, dict_entries, n_values, s);
+  switch (w) {
+    IPS_CASE(0) IPS_CASE(1) IPS_CASE(2) IPS_CASE(3) IPS_CASE(4) IPS_CASE(5) IPS_CASE(6) IPS_CASE(7)
+  }
+#undef IPS_CASE
+  set_error("bit width %d outside part starting at %d", w, IPS_WLO);
+  return IPS_ERR_INVALID_ARG;
+}
+
+// ---- the paged kernels: one launch over a run of pages of one bit width (blockIdx.y = page) ----
+template <int W, int KIND>
+static ips_status launch_pred_pages_wk(const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
+                                       const PredArgs& args, uint32_t* bitmap32, hipStream_t s) {
+  auto kern = fle_pred_pages_kernel<W, KIND>;
+  const int64_t tiles = (max_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int gx = paged_grid_x(reinterpret_cast<const void*>(kern), tiles, n_pages);
+  if (gx <= 0) return IPS_ERR_HIP;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)n_pages), dim3(kThreads), 0, s, d_pages, chunk_rows, args, bitmap32);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+template <int W>
+static ips_status launch_pred_pages_w(const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
+                                      const PredArgs& args, uint32_t* bitmap32, hipStream_t s) {
+  if constexpr (W == 32) {
+    static const bool early = dev_env("IPS_NO_EARLY_PRUNE") == nullptr;
+    if (early && args.op != 5) {
+      const int64_t tiles = (max_rows + kRowsPerTile - 1) / kRowsPerTile;
+      auto kern = args.join != 0 ? fle_pred32_early_pages_kernel<32, true> : fle_pred32_early_pages_kernel<32, false>;
+      const int gx = paged_grid_x(reinterpret_cast<const void*>(kern), tiles, n_pages);
+      if (gx <= 0) return IPS_ERR_HIP;
+      hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)n_pages), dim3(kThreads), 0, s, d_pages, chunk_rows, args, bitmap32);
+      IPS_HIP_TRY(hipGetLastError());
+      return IPS_OK;
+    }
+  }
+#define IPS_P(KIND) launch_pred_pages_wk<W, KIND>(d_pages, n_pages, max_rows, chunk_rows, args, bitmap32, s)
+  if (args.join != 0) return IPS_P(kPredPair);
+  if (args.op == 5) {
+    if constexpr (W <= 16) {
+      if (args.n_consts >= in_table_min_pred(W)) return IPS_P(kPredInTable);
+    }
+    return IPS_P(kPredInList);
+  }
+  return IPS_P(kPredSingle);
+#undef IPS_P
+}
+
+ips_status IPS_CAT(launch_fle_pred_pages_part_, IPS_PART)(int w, const ChunkPage* d_pages, int n_pages, int64_t max_rows,
+                                                          int64_t chunk_rows, const PredArgs& args, uint32_t* bitmap32,
+                                                          hipStream_t s) {
+#define IPS_CASE(N) \
+  case IPS_WLO + N: return launch_pred_pages_w<IPS_WLO + N>(d_pages, n_pages, max_rows, chunk_rows, args, bitmap32, s);
+  switch (w) {
+    IPS_CASE(0) IPS_CASE(1) IPS_CASE(2) IPS_CASE(3) IPS_CASE(4) IPS_CASE(5) IPS_CASE(6) IPS_CASE(7)
+  }
+#undef IPS_CASE
+  set_error("bit width %d outside part starting at %d", w, IPS_WLO);
+  return IPS_ERR_INVALID_ARG;
+}
+
+// the nullable leaf per page: grid.x = quarter rank tiles of the largest page
+template <int W>
+static ips_status launch_leaf_pages_w(const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
+                                      const PredArgs& args, uint32_t* bitmap32, hipStream_t s) {
+  const int64_t n_words = (max_rows + 63) / 64;
+  const dim3 grid((unsigned)((n_words + kExpWordsPerBlock - 1) / kExpWordsPerBlock), (unsigned)n_pages);
+#define IPS_L(KIND) \
+  hipLaunchKernelGGL((fle_leaf_pages_kernel<W, KIND>), grid, dim3(kThreads), 0, s, d_pages, chunk_rows, args, bitmap32)
+  if (args.join != 0) {
+    IPS_L(kPredPair);
+  } else if (args.op == 5) {
+    bool table = false;
+    if constexpr (W <= 16) {
+      if (args.n_consts >= in_table_min_pred(W)) {
+        IPS_L(kPredInTable);
+        table = true;
+      }
+    }
+    if (!table) IPS_L(kPredInList);
+  } else {
+    IPS_L(kPredSingle);
+  }
+#undef IPS_L
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+ips_status IPS_CAT(launch_fle_leaf_pages_part_, IPS_PART)(int w, const ChunkPage* d_pages, int n_pages, int64_t max_rows,
+                                                          int64_t chunk_rows, const PredArgs& args, uint32_t* bitmap32,
+                                                          hipStream_t s) {
+#define IPS_CASE(N) \
+  case IPS_WLO + N: return launch_leaf_pages_w<IPS_WLO + N>(d_pages, n_pages, max_rows, chunk_rows, args, bitmap32, s);
+  switch (w) {
+    IPS_CASE(0) IPS_CASE(1) IPS_CASE(2) IPS_CASE(3) IPS_CASE(4) IPS_CASE(5) IPS_CASE(6) IPS_CASE(7)
+  }
+#undef IPS_CASE
+  set_error("bit width %d outside part starting at %d", w, IPS_WLO);
+  return IPS_ERR_INVALID_ARG;
+}
+
+// fused scan / late materialisation over the pages of a chunk
+template <int W, int MODE, int G>
+static ips_status launch_scan_chunk_one(const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
+                                        const PredArgs& args, uint32_t* bitmap32, const uint32_t* given32,
+                                        void* batch_values, uint32_t* batch_counts, const void* dict,
+                                        uint32_t dict_entries, int32_t* bad_index, hipStream_t s) {
+  using GT = typename GatherT<G>::type;
+  auto kern = fle_scan_chunk_kernel<W, MODE, G>;
+  const int64_t tiles = (max_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int gx = paged_grid_x(reinterpret_cast<const void*>(kern), tiles, n_pages);
+  if (gx <= 0) return IPS_ERR_HIP;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)n_pages), dim3(kThreads), 0, s, d_pages, chunk_rows, args,
+                     bitmap32, given32, reinterpret_cast<GT*>(batch_values), batch_counts,
+                     reinterpret_cast<const GT*>(dict), dict_entries, bad_index);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+template <int W>
+static ips_status launch_scan_chunk_w(int mode, int gather, const ChunkPage* d_pages, int n_pages, int64_t max_rows,
+                                      int64_t chunk_rows, const PredArgs& args, uint32_t* bitmap32,
+                                      const uint32_t* given32, void* batch_values, uint32_t* batch_counts,
+                                      const void* dict, uint32_t dict_entries, int32_t* bad_index, hipStream_t s) {
+#define IPS_ARGS d_pages, n_pages, max_rows, chunk_rows, args, bitmap32, given32, batch_values, batch_counts, dict, \
+                 dict_entries, bad_index, s
+  if (gather == 0) {
+    if (mode == kScanPredicate) return launch_scan_chunk_one<W, kScanPredicate, 0>(IPS_ARGS);
+    if (mode == kScanInList) {
+      if constexpr (W <= 16) {
+        if (args.n_consts >= in_table_min(W)) return launch_scan_chunk_one<W, kScanInTable, 0>(IPS_ARGS);
+      }
+      return launch_scan_chunk_one<W, kScanInList, 0>(IPS_ARGS);
+    }
+    return launch_scan_chunk_one<W, kScanGivenBitmap, 0>(IPS_ARGS);
+  }
+  if constexpr (W <= 16) {
+    if (mode == kScanPredicate) {
+      if (gather == 4) return launch_scan_chunk_one<W, kScanPredicate, 4>(IPS_ARGS);
+      if (gather == 8) return launch_scan_chunk_one<W, kScanPredicate, 8>(IPS_ARGS);
+    }
+    if (mode == kScanInList && args.n_consts >= in_table_min(W)) {
+      if (gather == 4) return launch_scan_chunk_one<W, kScanInTable, 4>(IPS_ARGS);
+      if (gather == 8) return launch_scan_chunk_one<W, kScanInTable, 8>(IPS_ARGS);
+    }
+    if (mode == kScanInList) {
+      if (gather == 4) return launch_scan_chunk_one<W, kScanInList, 4>(IPS_ARGS);
+      if (gather == 8) return launch_scan_chunk_one<W, kScanInList, 8>(IPS_ARGS);
+    }
+    if (mode == kScanGivenBitmap) {
+      if (gather == 4) return launch_scan_chunk_one<W, kScanGivenBitmap, 4>(IPS_ARGS);
+      if (gather == 8) return launch_scan_chunk_one<W, kScanGivenBitmap, 8>(IPS_ARGS);
+    }
+  }
+#undef IPS_ARGS
+  set_error("fused dictionary scan over pages: unsupported bit width %d / gather %d / mode %d", W, gather, mode);
+  return IPS_ERR_UNSUPPORTED;
+}
+
+ips_status IPS_CAT(launch_fle_scan_chunk_part_, IPS_PART)(
+    int w, int mode, int gather, const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
+    const PredArgs& args, uint32_t* bitmap32, const uint32_t* given32, void* batch_values, uint32_t* batch_counts,
+    const void* dict, uint32_t dict_entries, int32_t* bad_index, hipStream_t s) {
+#define IPS_CASE(N)                                                                                              \
+  case IPS_WLO + N:                                                                                              \
+    return launch_scan_chunk_w<IPS_WLO + N>(mode, gather, d_pages, n_pages, max_rows, chunk_rows, args, bitmap32, \
+                                            given32, batch_values, batch_counts, dict, dict_entries, bad_index, s);
   switch (w) {
     IPS_CASE(0) IPS_CASE(1) IPS_CASE(2) IPS_CASE(3) IPS_CASE(4) IPS_CASE(5) IPS_CASE(6) IPS_CASE(7)
   }

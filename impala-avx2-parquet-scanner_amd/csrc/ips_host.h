@@ -6,7 +6,30 @@
 #include "../../include/ips.h"
 #include "ips_device.h"
 
+#include <vector>
+
+// DictDecoder<T>'s state (dict-encoding.h:449-459): the sorted entries on the host (literal
+// translation) and on the device (gathers)
+struct ips_dict {
+  ips_type type;
+  int64_t n;
+  int elem;                     // sizeof(T)
+  int slot;                     // PLAIN slot / device entry bytes: 4 or 8
+  std::vector<uint8_t> host;    // n elements of sizeof(T), ascending
+  void* d_entries;              // n entries of 'slot' bytes (int8/int16 sign-extended to int32)
+};
+
 namespace ips {
+
+// Outcome of comparing against constants that do not fit in bw bits (the
+// reference is inconsistent there; the build defines it by the unsigned SQL meaning).
+enum ConstKind { kEvaluate = 0, kAllFalse = 1, kAllTrue = 2 };
+ips_status build_pred_args(int bw, ips_op op, const uint64_t* consts, int n_consts, PredArgs* args,
+                           ConstKind* kind, const char* fn);
+// DictDecoder<T>::Eq..In's literal -> code translation (dict-encoding.h:461-541)
+ips_status translate(const ips_dict* d, ips_op op, const void* literals, int n_literals, ips_xl_kind* kind,
+                     ips_op* fle_op, uint64_t* codes, int* n_codes);
+ips_status check_dict_call(const ips_dict* dict, ips_op op, const void* literals, int n_literals, const char* fn);
 
 // thread-local error text behind ips_last_error()
 void set_error(const char* fmt, ...);

@@ -22,7 +22,7 @@
 // stopped, so one path serves every selectivity.
 #include <string.h>
 
-#include "ips_host.h"
+#include "ips_chunk_host.h"
 
 namespace ips {
 
@@ -199,11 +199,13 @@ __device__ __forceinline__ int64_t plain_next_tile(int64_t tile, int64_t waves) 
 
 // SCAN = false: predicate only (bitmap set / and-ed / or-ed).  SCAN = true: bitmap + the selected
 // rows' slots per 2048-row batch + batch counts.
-template <typename T, typename S, bool SCAN>
-__global__ __launch_bounds__(kThreads) void plain_tile_kernel(const S* __restrict__ page, int64_t n_rows, int op,
-                                                              PlainLit<T> lit, uint32_t* __restrict__ bitmap32,
-                                                              S* __restrict__ batch_values,
-                                                              uint32_t* __restrict__ batch_counts) {
+// PAGED: page / n_rows are one page of a column chunk, the bitmap is the chunk's (the lane dwords go
+// through the page's window, ips_chunk_device.h), the batch outputs start at the page's first slot.
+template <typename T, typename S, bool SCAN, bool PAGED>
+__device__ __forceinline__ void plain_tile_body(const S* __restrict__ page, int64_t n_rows, int op,
+                                                const PlainLit<T>& lit, uint32_t* __restrict__ bitmap32,
+                                                S* __restrict__ batch_values, uint32_t* __restrict__ batch_counts,
+                                                const BitmapWindow* win) {
   using G = PlainGeom<S>;
   __shared__ __attribute__((aligned(16))) uint8_t lds_all[kWavesPerBlock * kPlainWaveBytes];
   const int lane = lane_id();
@@ -233,7 +235,14 @@ __global__ __launch_bounds__(kThreads) void plain_tile_kernel(const S* __restric
 
     uint32_t bm = plain_pair_dword<S>(m);
     const int64_t d = G::R == 32 ? tile * 64 + lane : tile * 32 + (lane >> 1);
-    if ((G::R == 32 || (lane & 1) == 0) && d < bm_dwords) {
+    if constexpr (PAGED) {
+      if (G::R == 32) {
+        window_emit(*win, d, true, bm, lit.combine);
+      } else {  // dword k of the tile sits in lane 2k: bring it to lane k, 32 dwords per tile
+        const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_bpermute((2 * lane) << 2, (int)bm);
+        window_emit(*win, tile * 32 + lane, lane < 32, mine, lit.combine);
+      }
+    } else if ((G::R == 32 || (lane & 1) == 0) && d < bm_dwords) {
       if (lit.combine == 1) bm &= bitmap32[d];
       else if (lit.combine == 2) bm |= bitmap32[d];
       IPS_BITMAP_STORE(bitmap32 + d, bm);
@@ -261,6 +270,26 @@ __global__ __launch_bounds__(kThreads) void plain_tile_kernel(const S* __restric
 }
 
 template <typename T, typename S, bool SCAN>
+__global__ __launch_bounds__(kThreads) void plain_tile_kernel(const S* __restrict__ page, int64_t n_rows, int op,
+                                                              PlainLit<T> lit, uint32_t* __restrict__ bitmap32,
+                                                              S* __restrict__ batch_values,
+                                                              uint32_t* __restrict__ batch_counts) {
+  plain_tile_body<T, S, SCAN, false>(page, n_rows, op, lit, bitmap32, batch_values, batch_counts, nullptr);
+}
+
+template <typename T, typename S, bool SCAN>
+__global__ __launch_bounds__(kThreads) void plain_tile_pages_kernel(const ChunkPage* __restrict__ pages, int64_t chunk_rows,
+                                                                    int op, PlainLit<T> lit, uint32_t* __restrict__ bitmap32,
+                                                                    S* __restrict__ batch_values,
+                                                                    uint32_t* __restrict__ batch_counts) {
+  const ChunkPage pg = pages[blockIdx.y];
+  const BitmapWindow win = bitmap_window(bitmap32, pg, chunk_rows);
+  plain_tile_body<T, S, SCAN, true>(reinterpret_cast<const S*>(pg.data), pg.n_rows, op, lit, nullptr,
+                                    SCAN ? batch_values + (int64_t)pg.batch0 * kRowsPerTile : nullptr,
+                                    SCAN ? batch_counts + pg.batch0 : nullptr, &win);
+}
+
+template <typename T, typename S, bool SCAN>
 static ips_status launch_plain_tiles(const void* page, int64_t n_rows, int op, const void* literals,
                                      int n_literals, int combine, int join, int op2, const void* literal2,
                                      uint64_t* bitmap, void* batch_values, uint32_t* batch_counts,
@@ -277,6 +306,28 @@ static ips_status launch_plain_tiles(const void* page, int64_t n_rows, int op, c
   const int grid = grid_for_tiles(reinterpret_cast<const void*>(kern), n_batches);  // a wave per batch
   if (grid <= 0) return IPS_ERR_HIP;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, s, reinterpret_cast<const S*>(page), n_rows, op, lit,
+                     reinterpret_cast<uint32_t*>(bitmap), reinterpret_cast<S*>(batch_values), batch_counts);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+template <typename T, typename S, bool SCAN>
+static ips_status launch_plain_tiles_pages(const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
+                                           int op, const void* literals, int n_literals, int combine, int join,
+                                           int op2, const void* literal2, uint64_t* bitmap, void* batch_values,
+                                           uint32_t* batch_counts, hipStream_t s) {
+  PlainLit<T> lit;
+  lit.n = n_literals;
+  lit.combine = combine;
+  lit.join = join;
+  lit.op2 = op2;
+  lit.v2 = literal2 ? *reinterpret_cast<const T*>(literal2) : T();
+  for (int i = 0; i < 16; ++i) lit.v[i] = i < n_literals ? reinterpret_cast<const T*>(literals)[i] : T();
+  auto kern = plain_tile_pages_kernel<T, S, SCAN>;
+  const int64_t max_batches = (max_rows + kRowsPerTile - 1) / kRowsPerTile;  // a wave per batch
+  const int gx = paged_grid_x(reinterpret_cast<const void*>(kern), max_batches, n_pages);
+  if (gx <= 0) return IPS_ERR_HIP;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)n_pages), dim3(kThreads), 0, s, d_pages, chunk_rows, op, lit,
                      reinterpret_cast<uint32_t*>(bitmap), reinterpret_cast<S*>(batch_values), batch_counts);
   IPS_HIP_TRY(hipGetLastError());
   return IPS_OK;
@@ -314,6 +365,30 @@ ips_status launch_plain_pred(int type, const void* page, int64_t n_rows, int op,
   IPS_PLAIN_TYPES(IPS_PL)
 #undef IPS_PL
   set_error("plain_pred: bad type %d", type);
+  return IPS_ERR_INVALID_ARG;
+}
+
+ips_status launch_plain_pred_pages(int type, const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
+                                   int op, const void* literals, int n_literals, uint64_t* bitmap, hipStream_t s,
+                                   int combine, int join, int op2, const void* literal2) {
+#define IPS_PL(T, S)                                                                                               \
+  return launch_plain_tiles_pages<T, S, false>(d_pages, n_pages, max_rows, chunk_rows, op, literals, n_literals,   \
+                                               combine, join, op2, literal2, bitmap, nullptr, nullptr, s)
+  IPS_PLAIN_TYPES(IPS_PL)
+#undef IPS_PL
+  set_error("plain_pred_pages: bad type %d", type);
+  return IPS_ERR_INVALID_ARG;
+}
+
+ips_status launch_plain_scan_pages(int type, const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
+                                   int op, const void* literals, int n_literals, int join, int op2, const void* literal2,
+                                   uint64_t* bitmap, void* batch_values, uint32_t* batch_counts, hipStream_t s) {
+#define IPS_PS(T, S)                                                                                             \
+  return launch_plain_tiles_pages<T, S, true>(d_pages, n_pages, max_rows, chunk_rows, op, literals, n_literals, 0, \
+                                              join, op2, literal2, bitmap, batch_values, batch_counts, s)
+  IPS_PLAIN_TYPES(IPS_PS)
+#undef IPS_PS
+  set_error("plain_scan_pages: bad type %d", type);
   return IPS_ERR_INVALID_ARG;
 }
 

@@ -14,9 +14,12 @@
 
 #include <atomic>
 
-#include "ips_host.h"
+#include "ips_chunk_host.h"
 
 namespace ips {
+
+void run_pred_args(int bw, int op, const uint64_t* consts, int n_consts, int join, int op2, uint64_t const2,
+                   int combine, PredArgs* a);  // ips_chunk.hip
 
 // how ips_eval_program evaluates a tree (ips_set_program_strategy; process-wide, AUTO by default)
 static std::atomic<int> g_program_strategy{IPS_PROGRAM_AUTO};
@@ -948,4 +951,145 @@ extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const
   }
   return launch_program(prog, n_rows, reinterpret_cast<uint32_t*>(d_bitmap),
                         reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same tree over column chunks held as LISTS OF PAGES (ips_chunk): what EvalSimplePredicates
+// does across ReadDataPage boundaries (hdfs-parquet-scanner.cc:1837-1855: every batch ends where
+// the first column's page ends; pages of different columns need not align).  Per operand and per
+// run of equally wide pages ONE launch (blockIdx.y = page); every page is evaluated in its own
+// block geometry and writes / ANDs / ORs its rows' bits at its row offset of the bitmap
+// (ips_chunk_device.h), so the concatenation of the reference's per-batch bitsets comes out
+// whatever the page boundaries are.  OPTIONAL chunks go through the paged nullable leaf; their
+// tile counts are one extra launch per column and call.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+size_t align256z(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct ChunkCtx {
+  uint32_t* rank[IPS_PROGRAM_MAX_COLS] = {};
+  bool counted[IPS_PROGRAM_MAX_COLS] = {};
+};
+
+ips_status emit_item_chunk(const ChainItem& it, int combine, const ips_chunk* const* chunks, int64_t n_rows,
+                           uint64_t* d_bitmap, ChunkCtx& ctx, hipStream_t s) {
+  const int col = it.a->column;
+  const ips_chunk* c = chunks[col];
+  if (c->pages.empty()) return IPS_OK;
+  uint32_t* bm32 = reinterpret_cast<uint32_t*>(d_bitmap);
+  if (c->encoding == IPS_COL_FLE) {
+    if (c->max_def_level > 0 && !ctx.counted[col]) {
+      int64_t max_rows = 0;
+      for (const ips_chunk::Run& run : c->runs) max_rows = run.max_rows > max_rows ? run.max_rows : max_rows;
+      ips_status st = launch_rank_counts_pages(c->d_pages, (int)c->pages.size(), max_rows, ctx.rank[col], s);
+      if (st != IPS_OK) return st;
+      ctx.counted[col] = true;
+    }
+    for (const ips_chunk::Run& run : c->runs) {
+      PredArgs args;
+      run_pred_args(run.bit_width, it.a->op, it.a->consts, it.a->n_consts, it.b ? it.join : 0, it.b ? it.b->op : 0,
+                    it.b ? it.b->consts[0] : 0, combine, &args);
+      ips_status st;
+      if (c->max_def_level > 0) {
+        args.aux_counts = ctx.rank[col];
+        st = launch_fle_leaf_pages(run.bit_width, c->d_pages + run.first, run.count, run.max_rows, n_rows, args, bm32, s);
+      } else {
+        st = launch_fle_pred_pages(run.bit_width, c->d_pages + run.first, run.count, run.max_rows, n_rows, args, bm32, s);
+      }
+      if (st != IPS_OK) return st;
+    }
+    return IPS_OK;
+  }
+  const int sz = (c->type == IPS_T_INT8) ? 1 : (c->type == IPS_T_INT16) ? 2
+               : (c->type == IPS_T_INT64 || c->type == IPS_T_DOUBLE) ? 8 : 4;
+  uint8_t lits[16 * 8], lit2[8];
+  for (int j = 0; j < it.a->n_consts; ++j) memcpy(lits + j * sz, &it.a->consts[j], (size_t)sz);
+  if (it.b) memcpy(lit2, &it.b->consts[0], (size_t)sz);
+  return launch_plain_pred_pages(c->type, c->d_pages, (int)c->pages.size(), c->runs[0].max_rows, n_rows, it.a->op,
+                                 lits, it.a->n_consts, d_bitmap, s, combine, it.b ? it.join : 0, it.b ? it.b->op : 0,
+                                 it.b ? lit2 : nullptr);
+}
+
+ips_status check_chunk_program(const ips_node* nodes, int n_nodes, const ips_chunk* const* chunks, int n_chunks,
+                               int64_t* n_rows) {
+  IPS_REQUIRE(nodes && n_nodes >= 1 && n_nodes <= IPS_PROGRAM_MAX_NODES,
+              "ips_eval_program_chunks: n_nodes %d not in 1..%d", n_nodes, IPS_PROGRAM_MAX_NODES);
+  IPS_REQUIRE(chunks && n_chunks >= 1 && n_chunks <= IPS_PROGRAM_MAX_COLS,
+              "ips_eval_program_chunks: n_chunks %d not in 1..%d", n_chunks, IPS_PROGRAM_MAX_COLS);
+  for (int c = 0; c < n_chunks; ++c) {
+    IPS_REQUIRE(chunks[c] != nullptr, "ips_eval_program_chunks: chunk %d is NULL", c);
+    IPS_REQUIRE(chunks[c]->n_rows == chunks[0]->n_rows,
+                "ips_eval_program_chunks: chunk %d holds %lld rows, chunk 0 %lld (the columns of one row group)", c,
+                (long long)chunks[c]->n_rows, (long long)chunks[0]->n_rows);
+  }
+  *n_rows = chunks[0]->n_rows;
+  for (int i = 0; i < n_nodes; ++i) {
+    const ips_node& nd = nodes[i];
+    if (nd.kind == IPS_NODE_LEAF) {
+      IPS_REQUIRE(nd.column >= 0 && nd.column < n_chunks, "ips_eval_program_chunks: node %d: bad column", i);
+      IPS_REQUIRE(nd.op >= IPS_OP_EQ && nd.op <= IPS_OP_IN, "ips_eval_program_chunks: node %d: bad op", i);
+      IPS_REQUIRE(nd.n_consts >= 1 && nd.n_consts <= 16 && (nd.op == IPS_OP_IN || nd.n_consts == 1),
+                  "ips_eval_program_chunks: node %d: bad constant count", i);
+    } else {
+      IPS_REQUIRE(nd.kind == IPS_NODE_AND || nd.kind == IPS_NODE_OR, "ips_eval_program_chunks: node %d: bad kind", i);
+    }
+  }
+  return IPS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ips_chunk_program_workspace_bytes(const ips_node* nodes, int n_nodes,
+                                                    const ips_chunk* const* chunks, int n_chunks) {
+  int64_t n_rows = 0;
+  if (check_chunk_program(nodes, n_nodes, chunks, n_chunks, &n_rows) != IPS_OK) return 0;
+  Plan pl;
+  if (!make_plan(nodes, n_nodes, &pl)) return 0;
+  size_t bytes = pl.n_slots > 1 ? plan_slot_bytes(n_rows) * (size_t)(pl.n_slots - 1) : 0;
+  for (int c = 0; c < n_chunks; ++c)
+    if (chunks[c]->max_def_level > 0 && column_used(nodes, n_nodes, c)) bytes += align256z((size_t)chunks[c]->rank_entries * 4);
+  return bytes;
+}
+
+extern "C" ips_status ips_eval_program_chunks(const ips_node* nodes, int n_nodes, const ips_chunk* const* chunks,
+                                              int n_chunks, uint64_t* d_bitmap, void* d_workspace,
+                                              ips_stream stream) {
+  int64_t n_rows = 0;
+  ips_status st = check_chunk_program(nodes, n_nodes, chunks, n_chunks, &n_rows);
+  if (st != IPS_OK) return st;
+  IPS_REQUIRE(n_rows == 0 || (d_bitmap && aligned16(d_bitmap)), "ips_eval_program_chunks: bitmap NULL or misaligned");
+  Plan pl;
+  if (!make_plan(nodes, n_nodes, &pl)) {
+    set_error("ips_eval_program_chunks: the nodes are not a postfix program that leaves one bitmap");
+    return IPS_ERR_INVALID_ARG;
+  }
+  if (n_rows == 0) return IPS_OK;
+  const size_t need = ips_chunk_program_workspace_bytes(nodes, n_nodes, chunks, n_chunks);
+  IPS_REQUIRE(need == 0 || (d_workspace && aligned16(d_workspace)),
+              "ips_eval_program_chunks: pass a workspace of ips_chunk_program_workspace_bytes() bytes");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  uint8_t* temp = reinterpret_cast<uint8_t*>(d_workspace);
+  const size_t slot_bytes = plan_slot_bytes(n_rows);
+  ChunkCtx ctx;
+  {
+    uint8_t* p = temp + slot_bytes * (size_t)(pl.n_slots > 1 ? pl.n_slots - 1 : 0);
+    for (int c = 0; c < n_chunks; ++c) {
+      if (chunks[c]->max_def_level <= 0 || !column_used(nodes, n_nodes, c)) continue;
+      ctx.rank[c] = reinterpret_cast<uint32_t*>(p);
+      p += align256z((size_t)chunks[c]->rank_entries * 4);
+    }
+  }
+  auto slot_ptr = [&](int slot) -> uint64_t* {
+    if (slot == pl.root) return d_bitmap;
+    return reinterpret_cast<uint64_t*>(temp + slot_bytes * (size_t)(slot < pl.root ? slot : slot - 1));
+  };
+  for (int i = 0; i < pl.n_steps && st == IPS_OK; ++i) {
+    const Step& p = pl.steps[i];
+    if (p.kind == 0)
+      st = emit_item_chunk(ChainItem{false, p.item.a, p.item.b, p.item.join}, p.combine, chunks, n_rows, slot_ptr(p.dst), ctx, s);
+    else
+      st = launch_bitmap_binop(p.combine == 1 ? 0 : 1, slot_ptr(p.dst), slot_ptr(p.src), (n_rows + 63) / 64, s);
+  }
+  return st;
 }

@@ -16,7 +16,7 @@
 //      time through a 256-entry table in LDS), optionally AND-ing / OR-ing into an existing
 //      bitmap (ips_eval_program's combine modes).
 // HBM traffic: def levels twice (n/8 bytes each), the data bitmap once in, the result once out.
-#include "ips_host.h"
+#include "ips_chunk_host.h"
 #include "ips_rank_device.h"
 
 namespace ips {
@@ -213,6 +213,27 @@ ips_status launch_rank_tile_counts(int root_kind, const uint64_t* root, int64_t 
     hipLaunchKernelGGL((rank_tile_counts_kernel<kRootLevels1, false>), dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, n_rows, tile_counts, (u64*)nullptr);
   else
     hipLaunchKernelGGL((rank_tile_counts_kernel<kRootBitmap, false>), dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, n_rows, tile_counts, (u64*)nullptr);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+// the same for every page of an OPTIONAL column chunk: blockIdx.y = page, its table at rank0
+__global__ __launch_bounds__(kRankThreads) void rank_tile_counts_pages_kernel(const ChunkPage* __restrict__ pages,
+                                                                             uint32_t* __restrict__ counts) {
+  const ChunkPage pg = pages[blockIdx.y];
+  const int64_t n_words = (pg.n_rows + 63) / 64;
+  const int64_t tiles = (n_words + kRankWordsPerTile - 1) / kRankWordsPerTile;
+  if ((int64_t)blockIdx.x >= tiles) return;  // (the grid is sized for the largest page)
+  rank_tile_counts_body<kRootLevels1, false>(reinterpret_cast<const u64*>(pg.levels), pg.n_rows, counts + pg.rank0,
+                                             blockIdx.x, tiles, nullptr);
+}
+
+ips_status launch_rank_counts_pages(const ChunkPage* d_pages, int n_pages, int64_t max_rows, uint32_t* counts,
+                                    hipStream_t s) {
+  const int64_t tiles = rank_tiles(max_rows);
+  if (tiles <= 0 || n_pages <= 0) return IPS_OK;
+  hipLaunchKernelGGL(rank_tile_counts_pages_kernel, dim3((unsigned)tiles, (unsigned)n_pages), dim3(kRankThreads), 0, s,
+                     d_pages, counts);
   IPS_HIP_TRY(hipGetLastError());
   return IPS_OK;
 }

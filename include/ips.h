@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IPS_VERSION 200 /* 0.2.0: caller workspaces for ips_eval_program / ips_dict_encode, nullable leaves */
+#define IPS_VERSION 300 /* 0.3.0: column chunks as page lists (ips_chunk_*), ips_set_program_strategy */
 
 typedef enum {
   IPS_OK = 0,
@@ -399,6 +399,69 @@ size_t ips_program_workspace_bytes(const ips_node* nodes, int n_nodes, const ips
 ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const ips_column* cols, int n_cols,
                             int64_t n_rows, uint64_t* d_bitmap, void* d_workspace,
                             ips_stream stream);
+
+/* ---- column chunks as lists of pages --------------------------------------------------------- */
+/* A column reader holds its chunk as data pages (ReadDataPage / InitDataPage per page,
+ * hdfs-parquet-scanner.cc:730-924) whose row counts are the writer's choice: pages of different
+ * columns end at different rows and EvalSimplePredicates cuts every batch at the page ends of all
+ * columns (:1837-1855).  An ips_chunk is that page list resident in HBM: the pages stay separate
+ * device buffers (no concatenation, no copy), every page keeps its own FLE block geometry (blocks
+ * of 64 rows start at the page's first row) and its own code width (the dictionary writer puts the
+ * width of each data page in its first byte and it grows with the dictionary, dict-encoding.h:
+ * 425-447).  Calls over a chunk cost one launch per run of equally wide pages, whatever the number
+ * of pages, and produce bitmaps over the chunk's rows: bit r <-> row r of the chunk = row
+ * r - row0(p) of its page p.  Rows need not be aligned to anything; a page may have any size >= 0.
+ * ips_chunk_open is synchronous (it uploads the page table); the calls over chunks only launch. */
+typedef struct {
+  const void* d_data;        /* FLE blocks (after the width byte SetData strips) or PLAIN slots of the page,
+                                16-byte aligned; OPTIONAL chunks: of the page's non-NULL rows only */
+  int64_t n_rows;            /* rows of the page, NULLs included (DataPageHeader.num_values) */
+  int32_t bit_width;         /* FLE: the page's width, 1..32 */
+  int32_t reserved;
+  const void* d_def_levels;  /* OPTIONAL chunks: FLE blocks (width 1) of the page's n_rows definition levels */
+  int64_t n_data_rows;       /* OPTIONAL chunks: rows d_data holds (see ips_fle_pred_nullable) */
+} ips_chunk_page;
+typedef struct ips_chunk ips_chunk;
+/* encoding: ips_col_encoding; type: PLAIN chunks; max_def_level: 0 REQUIRED, 1 OPTIONAL (FLE /
+ * dictionary chunks of a flat schema -- what the reference's vectorised path handles, :338-348;
+ * anything else is IPS_ERR_UNSUPPORTED).  The page buffers must outlive the handle's use. */
+ips_status ips_chunk_open(const ips_chunk_page* h_pages, int n_pages, int encoding, ips_type type,
+                          int max_def_level, ips_chunk** chunk);
+ips_status ips_chunk_close(ips_chunk* chunk);
+int64_t ips_chunk_num_rows(const ips_chunk* chunk);
+/* batch slots of the chunk's fused scans: the sum over the pages of ceil(rows / IPS_BATCH_ROWS) */
+int64_t ips_chunk_num_batches(const ips_chunk* chunk);
+int ips_chunk_num_pages(const ips_chunk* chunk); /* the non-empty pages */
+
+/* ips_eval_program over chunks: leaf.column indexes 'chunks', which all hold the same number of rows
+ * (the column chunks of one row group).  FLE constants that do not fit a page's width are folded per
+ * page (always false / always true on that page); PLAIN leaves have SQL semantics, as in
+ * ips_eval_program.  d_bitmap: ceil(rows / 64) words.  Workspace: ips_chunk_program_workspace_bytes(). */
+size_t ips_chunk_program_workspace_bytes(const ips_node* nodes, int n_nodes,
+                                         const ips_chunk* const* chunks, int n_chunks);
+ips_status ips_eval_program_chunks(const ips_node* nodes, int n_nodes, const ips_chunk* const* chunks,
+                                   int n_chunks, uint64_t* d_bitmap, void* d_workspace,
+                                   ips_stream stream);
+
+/* The fused scans over a REQUIRED chunk: ips_fle_scan / ips_dict_scan / ips_plain_scan with the
+ * page loop inside the launch.  d_bitmap is the chunk's; the batch list is the concatenation of the
+ * pages' batches (a page's last batch is partial): ips_chunk_num_batches() batches of
+ * IPS_BATCH_ROWS slots and as many counts, in row order, which ips_batches_compact turns into one
+ * dense array (pass ips_chunk_num_batches() * IPS_BATCH_ROWS as its n_rows). */
+ips_status ips_chunk_fle_scan(const ips_chunk* chunk, ips_op op, const uint64_t* consts, int n_consts,
+                              uint64_t* d_bitmap, uint32_t* d_batch_values, uint32_t* d_batch_counts,
+                              ips_stream stream);
+ips_status ips_chunk_dict_scan(const ips_chunk* chunk, const ips_dict* dict, ips_op op,
+                               const void* literals, int n_literals, uint64_t* d_bitmap,
+                               void* d_batch_values, uint32_t* d_batch_counts, ips_stream stream);
+ips_status ips_chunk_plain_scan(const ips_chunk* chunk, ips_op op, const void* literals, int n_literals,
+                                ips_op op2, const void* literal2, ips_semantics semantics,
+                                uint64_t* d_bitmap, void* d_batch_values, uint32_t* d_batch_counts,
+                                ips_stream stream);
+/* Late materialisation of a REQUIRED FLE / dictionary chunk against a selection over the chunk's
+ * rows (ips_fle_select / ips_dict_select with the page loop inside; dict NULL: the FLE values). */
+ips_status ips_chunk_select(const ips_chunk* chunk, const ips_dict* dict, const uint64_t* d_bitmap,
+                            void* d_batch_values, uint32_t* d_batch_counts, ips_stream stream);
 
 /* ---- multi-GPU exchange (one process per GPU) ------------------------------------------------ */
 /* The path shards by row stripes (blocks of 64 rows are independent, hdfs-parquet-scanner.cc:
