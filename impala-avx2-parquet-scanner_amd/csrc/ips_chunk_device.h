@@ -73,6 +73,9 @@ __device__ __forceinline__ void window_put(uint32_t* p, uint32_t val, uint32_t m
     IPS_BITMAP_STORE(p, val);
     return;
   }
+#ifdef IPS_WINDOW_ABLATE  // dev (timing only, results are wrong): no merging of shared dwords
+  return;
+#endif
   if (combine == 0) {
     atomicAnd(p, ~mask);
     if (val) atomicOr(p, val);
@@ -83,39 +86,66 @@ __device__ __forceinline__ void window_put(uint32_t* p, uint32_t val, uint32_t m
   }
 }
 
-// The wave holds a run of consecutive page-relative bitmap dwords, lane l the dword d = d0 + l: 'bm'
-// (bit j <-> row 32 d + j of the page, rows beyond the page already cleared).  Lanes that hold no
-// dword of their own pass active = false (they still deliver the high part of the lane before
-// them).  Every lane of the wave calls it.  combine: 0 store, 1 AND into, 2 OR into.
-__device__ __forceinline__ void window_emit(const BitmapWindow& w, int64_t d, bool active, uint32_t bm, int combine) {
+// A wave works through CONSECUTIVE runs of page-relative bitmap dwords (sub-tile after sub-tile of
+// its share of the page).  With a shifted window the high part of a run's last lane belongs to the
+// first dword of the next run: it is carried there in two scalar registers instead of being merged
+// through memory, so that only the two ends of a wave's whole share touch dwords that another wave
+// also writes (atomics: two per share, not two per sub-tile -- which cost the unaligned Q6 plan
+// 2.6x: 900 us against 344 us, profiles/round3_chunks.md).
+struct WindowCarry {
+  uint32_t bm = 0u, vm = 0u;  // the previous run's last lane: its dword and the rows it owns (unshifted)
+  int64_t next = -1;          // page-relative dword that follows the previous run; -1: nothing carried
+};
+
+// what is still carried goes out (the end of a wave's share, or a gap in its runs)
+__device__ __forceinline__ void window_flush(const BitmapWindow& w, WindowCarry& cy, int combine) {
+  if (cy.next >= 0 && w.shift != 0u && cy.vm != 0u && (threadIdx.x & (kWave - 1)) == 0) {
+    const uint32_t r = 32u - w.shift;
+    uint32_t m2 = cy.vm >> r;
+    const bool tail = w.own_tail && cy.next == w.tail_dword && m2 != 0u;
+    if (tail) m2 |= w.tail_mask;
+    window_put(w.base + cy.next, cy.bm >> r, m2, combine);
+    if (tail && w.tail_extra && combine != 2) IPS_BITMAP_STORE(w.base + cy.next + 1, 0u);
+  }
+  cy.next = -1;
+  cy.bm = cy.vm = 0u;
+}
+
+// One run: lane l holds the page-relative dword d = d0 + l ('bm': bit j <-> row 32 d + j of the page)
+// for l <= last_lane (63, or 31 when only half the wave holds dwords); every lane of the wave calls
+// it.  combine: 0 store, 1 AND into, 2 OR into.
+__device__ __forceinline__ void window_emit(const BitmapWindow& w, WindowCarry& cy, int64_t d, uint32_t bm, int combine,
+                                            int last_lane = kWave - 1) {
+  const int lane = (int)(threadIdx.x & (kWave - 1));
   const int64_t valid = w.n_rows - d * 32;
-  const uint32_t vm = !active ? 0u : valid >= 32 ? ~0u : valid <= 0 ? 0u : ((1u << valid) - 1u);
+  const uint32_t vm = lane > last_lane ? 0u : valid >= 32 ? ~0u : valid <= 0 ? 0u : ((1u << valid) - 1u);
   bm &= vm;
   uint32_t val = bm, mask = vm;
   if (w.shift != 0u) {  // wave-uniform
+    const int64_t d0 = d - lane;
+    if (cy.next != d0) window_flush(w, cy, combine);  // (not the run that follows the carried one)
     const uint32_t s = w.shift, r = 32u - s;
-    const uint32_t up_bm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bm, 0x138, 0xF, 0xF, true);  // wave_shr:1
-    const uint32_t up_vm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vm, 0x138, 0xF, 0xF, true);  // (lane 0: 0)
+    uint32_t up_bm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bm, 0x138, 0xF, 0xF, true);  // wave_shr:1
+    uint32_t up_vm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vm, 0x138, 0xF, 0xF, true);
+    if (lane == 0) { up_bm = cy.bm; up_vm = cy.vm; }
     val = (bm << s) | (up_bm >> r);
     mask = (vm << s) | (up_vm >> r);
+    if (lane > last_lane) mask = 0u;  // (the last lane's high part travels in the carry)
+    cy.bm = (uint32_t)__builtin_amdgcn_readlane((int)bm, last_lane);
+    cy.vm = (uint32_t)__builtin_amdgcn_readlane((int)vm, last_lane);
+    cy.next = d0 + last_lane + 1;
   }
   const bool tail = w.own_tail && d == w.tail_dword && mask != 0u;  // zeros behind the chunk's last row
   if (tail) mask |= w.tail_mask;
   window_put(w.base + d, val, mask, combine);
   if (tail && w.tail_extra && combine != 2) IPS_BITMAP_STORE(w.base + d + 1, 0u);
-  if (w.shift != 0u && (threadIdx.x & (kWave - 1)) == kWave - 1 && vm != 0u) {  // the last lane's high part: dword d + 1
-    const uint32_t v2 = bm >> (32u - w.shift);
-    uint32_t m2 = vm >> (32u - w.shift);
-    const bool tail2 = w.own_tail && d + 1 == w.tail_dword && m2 != 0u;
-    if (tail2) m2 |= w.tail_mask;
-    window_put(w.base + d + 1, v2, m2, combine);
-    if (tail2 && w.tail_extra && combine != 2) IPS_BITMAP_STORE(w.base + d + 2, 0u);
-  }
 }
 
 // The same for a wave whose lanes hold FOUR consecutive dwords each (two 64-bit words per lane, the
 // nullable leaf): in[k] = page-relative dword d0 + k, lane l + 1 continues where lane l ends.
-__device__ __forceinline__ void window_emit_quad(const BitmapWindow& w, int64_t d0, const uint32_t (&in)[4], int combine) {
+__device__ __forceinline__ void window_emit_quad(const BitmapWindow& w, WindowCarry& cy, int64_t d0,
+                                                 const uint32_t (&in)[4], int combine) {
+  const int lane = (int)(threadIdx.x & (kWave - 1));
   uint32_t bm[4], vm[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -126,8 +156,16 @@ __device__ __forceinline__ void window_emit_quad(const BitmapWindow& w, int64_t 
   const uint32_t s = w.shift, r = 32u - s;
   uint32_t pb = 0u, pv = 0u;
   if (s != 0u) {  // wave-uniform
-    pb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bm[3], 0x138, 0xF, 0xF, true) >> r;  // wave_shr:1 (lane 0: 0)
-    pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vm[3], 0x138, 0xF, 0xF, true) >> r;
+    const int64_t run0 = d0 - 4 * lane;
+    if (cy.next != run0) window_flush(w, cy, combine);
+    pb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bm[3], 0x138, 0xF, 0xF, true);  // wave_shr:1
+    pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vm[3], 0x138, 0xF, 0xF, true);
+    if (lane == 0) { pb = cy.bm; pv = cy.vm; }
+    pb >>= r;
+    pv >>= r;
+    cy.bm = (uint32_t)__builtin_amdgcn_readlane((int)bm[3], kWave - 1);
+    cy.vm = (uint32_t)__builtin_amdgcn_readlane((int)vm[3], kWave - 1);
+    cy.next = run0 + 4 * kWave;
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -140,13 +178,22 @@ __device__ __forceinline__ void window_emit_quad(const BitmapWindow& w, int64_t 
     pb = s != 0u ? bm[k] >> r : 0u;
     pv = s != 0u ? vm[k] >> r : 0u;
   }
-  if (s != 0u && (threadIdx.x & (kWave - 1)) == kWave - 1 && pv != 0u) {  // the last lane's high part
-    uint32_t m2 = pv;
-    const bool tail2 = w.own_tail && d0 + 4 == w.tail_dword;
-    if (tail2) m2 |= w.tail_mask;
-    window_put(w.base + d0 + 4, pb, m2, combine);
-    if (tail2 && w.tail_extra && combine != 2) IPS_BITMAP_STORE(w.base + d0 + 5, 0u);
-  }
+}
+
+// The sub-tiles a wave takes of a page with 'tiles' sub-tiles: every wave-th one when the window is
+// dword aligned (neighbouring waves stream neighbouring bytes), else ONE contiguous share, so that
+// the carry above covers all but the share's two ends.
+struct TileShare { int64_t first, step, end; };
+__device__ __forceinline__ TileShare tile_share(const BitmapWindow& w, int64_t tiles, int64_t wave_index, int64_t n_waves) {
+  if (w.shift == 0u) return TileShare{wave_index, n_waves, tiles};
+  // at least kMinShare sub-tiles per share (the waves behind the last share find nothing to do):
+  // the two shared dwords of a share cost four atomics, 2^20-row pages of a narrow column would
+  // otherwise be cut into shares of five sub-tiles (Q6 over unaligned pages: 476 -> 4xx us)
+  constexpr int64_t kMinShare = IPS_MIN_SHARE;
+  int64_t q = (tiles + n_waves - 1) / n_waves;
+  q = q < kMinShare ? kMinShare : q;
+  const int64_t first = wave_index * q;
+  return TileShare{first, 1, first + q < tiles ? first + q : tiles};
 }
 
 // The other direction: this lane's dword of a selection over the chunk's rows (bit j <-> row

@@ -138,7 +138,8 @@ __device__ __forceinline__ void fle_scan_body(
     uint32_t* __restrict__ bitmap32, const uint32_t* __restrict__ given_bitmap32,
     typename GatherT<G>::type* __restrict__ batch_values, uint32_t* __restrict__ batch_counts,
     const typename GatherT<G>::type* __restrict__ dict, uint32_t dict_entries,
-    int32_t* __restrict__ bad_index, int64_t first_tile, int64_t stride, const PageCtx* pc = nullptr) {
+    int32_t* __restrict__ bad_index, int64_t first_tile, int64_t stride, const PageCtx* pc = nullptr,
+    int64_t tile_end = -1) {
   constexpr int kWB = ScanLds<W, MODE>::kWaveBytes;
   constexpr bool kSmallLds = ScanLds<W, MODE>::kSmall;
   constexpr bool kWindowed = ScanLds<W, MODE>::kWindowed;
@@ -166,10 +167,12 @@ __device__ __forceinline__ void fle_scan_body(
   __shared__ uint32_t in_table[kInTable ? InTable<W>::kDwords : 1];
   if constexpr (kInTable) in_table_build<W>(in_table, args);
 
-  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  // (PAGED: 'tiles' is the end of this wave's share of the page's sub-tiles)
+  const int64_t tiles = PAGED ? tile_end : (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   const int64_t total_words = ((n_rows + 63) / 64) * W;
   const int64_t bm_dwords = bitmap_dwords(n_rows);
   int64_t tile = first_tile;
+  [[maybe_unused]] WindowCarry carry;
 
   // given bitmap: this lane's dword of the sub-tile, and which blocks hold a selected row
   auto given_dword = [&](int64_t t) -> uint32_t {
@@ -183,7 +186,7 @@ __device__ __forceinline__ void fle_scan_body(
   // this lane's bitmap dword of sub-tile t (rows beyond n_rows cleared) -> the bitmap
   auto put_dword = [&](int64_t t, uint32_t dword) {
     if constexpr (PAGED) {
-      window_emit(pc->win, t * 64 + lane, true, dword, 0);
+      window_emit(pc->win, carry, t * 64 + lane, dword, 0);
     } else {
       const int64_t dd = t * 64 + lane;
       if (dd < bm_dwords) IPS_BITMAP_STORE(bitmap32 + dd, dword);
@@ -513,6 +516,7 @@ __device__ __forceinline__ void fle_scan_body(
     wave_lds_fence();  // LDS region is reused by the next sub-tile
     tile = next;
   }
+  if constexpr (PAGED && MODE != kScanGivenBitmap) window_flush(pc->win, carry, 0);
 }
 
 template <int W, int MODE, int G>
@@ -575,11 +579,12 @@ __global__ __launch_bounds__(kThreads, (ScanLds<W, MODE>::kMinWaves)) void fle_s
   pc.page = pages[blockIdx.y];
   pc.win = bitmap_window(bitmap32, pc.page, chunk_rows);
   pc.total_dwords = bitmap_dwords(chunk_rows);
+  const TileShare sh = tile_share(pc.win, (pc.page.n_data + kRowsPerTile - 1) / kRowsPerTile,
+                                  (int64_t)blockIdx.x * kWavesPerBlock + wave_id(), (int64_t)gridDim.x * kWavesPerBlock);
   fle_scan_body<W, MODE, G, true>(pc.page.data, pc.page.n_data, args, nullptr, given_bitmap32,
                                   batch_values + (int64_t)pc.page.batch0 * kRowsPerTile,
-                                  batch_counts + pc.page.batch0, dict, dict_entries, bad_index,
-                                  (int64_t)blockIdx.x * kWavesPerBlock + wave_id(),
-                                  (int64_t)gridDim.x * kWavesPerBlock, &pc);
+                                  batch_counts + pc.page.batch0, dict, dict_entries, bad_index, sh.first, sh.step,
+                                  &pc, sh.end);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -604,11 +609,18 @@ __device__ __forceinline__ void fle_pred_body(const uint64_t* __restrict__ enc, 
   const int wave = wave_id();
   uint32_t* lds32 = lds_all + wave * (plane_tile_bytes(W) / 4);
 
-  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   const int64_t total_words = ((n_rows + 63) / 64) * W;
-  const int64_t stride = (int64_t)((int)gridDim.x - args.aux_blocks) * kWavesPerBlock;
+  int64_t stride = (int64_t)((int)gridDim.x - args.aux_blocks) * kWavesPerBlock;
   const int64_t bm_dwords = bitmap_dwords(n_rows);
   int64_t tile = (int64_t)((int)blockIdx.x - args.aux_blocks) * kWavesPerBlock + wave;
+  [[maybe_unused]] WindowCarry carry;
+  if constexpr (PAGED) {  // this wave's share of the page's sub-tiles
+    const TileShare sh = tile_share(*win, tiles, tile, stride);
+    tile = sh.first;
+    stride = sh.step;
+    tiles = sh.end;
+  }
   constexpr bool kInTable = KIND == kPredInTable && InTable<W>::kUse;
   __shared__ uint32_t in_table[kInTable ? InTable<W>::kDwords : 1];
   if constexpr (kInTable) in_table_build<W>(in_table, args);
@@ -645,7 +657,7 @@ __device__ __forceinline__ void fle_pred_body(const uint64_t* __restrict__ enc, 
     uint32_t bm = finish_bitmap_dword(sel, tile, lane, n_rows);
     const int64_t d = tile * 64 + lane;
     if constexpr (PAGED) {
-      window_emit(*win, d, true, bm, args.combine);
+      window_emit(*win, carry, d, bm, args.combine);
     } else if (d < bm_dwords) {
       if (args.combine == 1) bm &= bitmap32[d];
       else if (args.combine == 2) bm |= bitmap32[d];
@@ -654,6 +666,7 @@ __device__ __forceinline__ void fle_pred_body(const uint64_t* __restrict__ enc, 
     wave_lds_fence();  // LDS region is reused by the next sub-tile
     tile = next;
   }
+  if constexpr (PAGED) window_flush(*win, carry, args.combine);
 }
 
 template <int W, int KIND>
@@ -896,6 +909,7 @@ __device__ __forceinline__ void fle_leaf_body(const uint64_t* __restrict__ enc, 
   }
 
   // deposit: the window of a word = three segment dwords from its rank on
+  [[maybe_unused]] WindowCarry carry;
 #pragma unroll
   for (int r2 = 0; r2 < kExpRounds; ++r2) {
     const int64_t w0 = first + r2 * 128 + 2 * lane;
@@ -921,7 +935,7 @@ __device__ __forceinline__ void fle_leaf_body(const uint64_t* __restrict__ enc, 
       // else goes dword by dword through the window (shifted, shared dwords merged atomically)
       if (!(whole && win->shift == 0u && (reinterpret_cast<uintptr_t>(win->base) & 15u) == 0u)) {
         const uint32_t in[4] = {(uint32_t)res[0], (uint32_t)(res[0] >> 32), (uint32_t)res[1], (uint32_t)(res[1] >> 32)};
-        window_emit_quad(*win, 2 * w0, in, args.combine);
+        window_emit_quad(*win, carry, 2 * w0, in, args.combine);
         continue;
       }
     }
@@ -940,6 +954,7 @@ __device__ __forceinline__ void fle_leaf_body(const uint64_t* __restrict__ enc, 
       out[w0] = res[0];
     }
   }
+  if constexpr (PAGED) window_flush(*win, carry, args.combine);
 }
 
 template <int W, int KIND>
@@ -1273,9 +1288,9 @@ __device__ __forceinline__ void fle_pred32_early_body(const uint64_t* __restrict
   const int lane = lane_id();
   const int wave = wave_id();
   uint32_t* lds32 = lds_all + wave * (plane_tile_bytes(W) / 4);
-  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   const int64_t total_words = ((n_rows + 63) / 64) * W;
-  const int64_t stride = (int64_t)((int)gridDim.x - args.aux_blocks) * kWavesPerBlock;
+  int64_t stride = (int64_t)((int)gridDim.x - args.aux_blocks) * kWavesPerBlock;
   const int64_t bm_dwords = bitmap_dwords(n_rows);
   const uint32_t c = args.consts[0];
   const uint32_t c2 = args.const2;
@@ -1322,6 +1337,13 @@ __device__ __forceinline__ void fle_pred32_early_body(const uint64_t* __restrict
   };
 
   int64_t tile = (int64_t)((int)blockIdx.x - args.aux_blocks) * kWavesPerBlock + wave;
+  [[maybe_unused]] WindowCarry carry;
+  if constexpr (PAGED) {  // this wave's share of the page's sub-tiles
+    const TileShare sh = tile_share(*win, tiles, tile, stride);
+    tile = sh.first;
+    stride = sh.step;
+    tiles = sh.end;
+  }
   bool with_low = false;  // wave-uniform: the previous sub-tile needed the low planes
   u32x4 rh[4], rl[4];
   if (tile < tiles) load_half(tile, 1, rh);
@@ -1362,7 +1384,7 @@ __device__ __forceinline__ void fle_pred32_early_body(const uint64_t* __restrict
     uint32_t bm = finish_bitmap_dword(sel, tile, lane, n_rows);
     const int64_t d = tile * 64 + lane;
     if constexpr (PAGED) {
-      window_emit(*win, d, true, bm, args.combine);
+      window_emit(*win, carry, d, bm, args.combine);
     } else if (d < bm_dwords) {
       if (args.combine == 1) bm &= bitmap32[d];
       else if (args.combine == 2) bm |= bitmap32[d];
@@ -1371,6 +1393,7 @@ __device__ __forceinline__ void fle_pred32_early_body(const uint64_t* __restrict
     wave_lds_fence();  // LDS region is reused by the next sub-tile
     tile = next;
   }
+  if constexpr (PAGED) window_flush(*win, carry, args.combine);
 }
 
 template <int W, bool PAIR>

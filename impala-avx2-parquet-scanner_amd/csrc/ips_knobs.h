@@ -15,7 +15,8 @@
     defined(IPS_SCAN_SMALL_LDS) || defined(IPS_SCAN_SMALL_LDS_MAX_W) || defined(IPS_ABLATE) ||          \
     defined(IPS_GATHER_WIDE) || defined(IPS_GATHER_MAX_4) || defined(IPS_QUADS) || defined(IPS_QUADS16) || \
     defined(IPS_PHASE_B_GROUP) || defined(IPS_NT_VALUE_STORE) || defined(IPS_DECODE_PACKED) ||          \
-    defined(IPS_EXP_ROUNDS) || defined(IPS_AUX_NT) || defined(IPS_PLAIN_ABLATE)
+    defined(IPS_EXP_ROUNDS) || defined(IPS_AUX_NT) || defined(IPS_PLAIN_ABLATE) || defined(IPS_MIN_SHARE) ||  \
+    defined(IPS_WINDOW_ABLATE)
 #error "development switches need -DIPS_DEV_KNOBS (the default library has none)"
 #endif
 #endif
@@ -74,6 +75,12 @@
 #ifndef IPS_PLAIN_ABLATE
 #define IPS_PLAIN_ABLATE 0  // timing only, RESULTS ARE WRONG: 1 drops the PLAIN scan's value stores, 2 the whole materialisation
 #endif
+
+// ---- page lists (ips_chunk_device.h) ---------------------------------------------------------
+#ifndef IPS_MIN_SHARE
+#define IPS_MIN_SHARE 8             // sub-tiles per contiguous share of a page whose window is shifted (1: Q6 unaligned 476 us, 16: 420 us but the w=32 scan 220 -> 263 us)
+#endif
+// IPS_WINDOW_ABLATE: defined = shared bitmap dwords are not merged (timing only, RESULTS ARE WRONG)
 
 // ---- rank tiles (ips_rank_device.h) ----------------------------------------------------------
 #ifndef IPS_EXP_ROUNDS

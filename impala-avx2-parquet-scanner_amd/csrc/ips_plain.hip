@@ -217,13 +217,23 @@ __device__ __forceinline__ void plain_tile_body(const S* __restrict__ page, int6
   const int64_t bm_dwords = bitmap_dwords(n_rows);
 
   int64_t tile = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * G::TPB;
+  int64_t batch_step = waves;
+  int64_t tiles_end = n_tiles;
+  [[maybe_unused]] WindowCarry carry;
+  if constexpr (PAGED) {  // this wave's share of the page's batches (contiguous when the window is shifted)
+    const TileShare sh = tile_share(*win, (n_rows + kRowsPerTile - 1) / kRowsPerTile,
+                                    (int64_t)blockIdx.x * kWavesPerBlock + wave, waves);
+    tile = sh.first * G::TPB;
+    batch_step = sh.step;
+    tiles_end = sh.end * G::TPB < n_tiles ? sh.end * G::TPB : n_tiles;
+  }
   u32x4 r[kPlainLoads];
-  if (tile < n_tiles) plain_tile_load<S>(page, tile, n_rows, lane, r);
+  if (tile < tiles_end) plain_tile_load<S>(page, tile, n_rows, lane, r);
   uint32_t base = 0;  // rows of the batch selected in its earlier tile (8-byte slots)
-  while (tile < n_tiles) {
+  while (tile < tiles_end) {
     plain_tile_stage(lds, lane, r);
-    const int64_t next = plain_next_tile<S>(tile, waves);
-    if (next < n_tiles) plain_tile_load<S>(page, next, n_rows, lane, r);  // register prefetch
+    const int64_t next = plain_next_tile<S>(tile, batch_step);
+    if (next < tiles_end) plain_tile_load<S>(page, next, n_rows, lane, r);  // register prefetch
     wave_lds_fence();
 
     uint32_t m = plain_lane_mask<T, S>(lds, lane, op, lit.v, lit.n);
@@ -237,10 +247,10 @@ __device__ __forceinline__ void plain_tile_body(const S* __restrict__ page, int6
     const int64_t d = G::R == 32 ? tile * 64 + lane : tile * 32 + (lane >> 1);
     if constexpr (PAGED) {
       if (G::R == 32) {
-        window_emit(*win, d, true, bm, lit.combine);
+        window_emit(*win, carry, d, bm, lit.combine);
       } else {  // dword k of the tile sits in lane 2k: bring it to lane k, 32 dwords per tile
         const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_bpermute((2 * lane) << 2, (int)bm);
-        window_emit(*win, tile * 32 + lane, lane < 32, mine, lit.combine);
+        window_emit(*win, carry, tile * 32 + lane, mine, lit.combine, 31);
       }
     } else if ((G::R == 32 || (lane & 1) == 0) && d < bm_dwords) {
       if (lit.combine == 1) bm &= bitmap32[d];
@@ -267,6 +277,7 @@ __device__ __forceinline__ void plain_tile_body(const S* __restrict__ page, int6
     wave_lds_fence();  // the image is rewritten by the next tile
     tile = next;
   }
+  if constexpr (PAGED) window_flush(*win, carry, lit.combine);
 }
 
 template <typename T, typename S, bool SCAN>
