@@ -240,7 +240,7 @@ def leg_nullable(capi, dev, n):
     n_sel = int(sel_rows.sum().item())
     dense = torch.empty(n_sel + 64, dtype=torch.int32, device=dev)
     flags = torch.empty((n + 63) // 64, dtype=torch.int64, device=dev)
-    cnts = torch.zeros(2, dtype=torch.int64, device=dev)
+    cnts = torch.zeros(3, dtype=torch.int64, device=dev)
     P = lambda t: C.c_void_p(t.data_ptr())
     stream = capi._stream(None)
 
@@ -248,7 +248,7 @@ def leg_nullable(capi, dev, n):
         capi._ck(lib.ips_dict_select_nullable(None, P(defs), 1, 1, C.c_int64(n), P(enc), C.c_int64(n_data), 12,
                                               P(bm), P(dense), P(flags), P(cnts), P(ws2), stream))
     tmed, tmin = time_launches(mat)
-    got = cnts.cpu().tolist()
+    got = cnts.cpu().tolist()[:2]
     ok2 = (got == [n_sel, n_sel] and torch.equal(dense[:n_sel], vals[vals < 409].to(torch.int32))
            and capi.bitmap_count(flags, n_sel) == n_sel)
     byts2 = (n + 63) // 64 * 8 * 2 + n_data // 64 * 12 * 8 + 4 * n_sel + n_sel // 8
@@ -286,6 +286,72 @@ def leg_q6_single(ips, capi, dev, O):
                 n, q6.algorithmic_bytes(n), tmed, tmin, bool(ok and ok_oracle),
                 selectivity=round(int(mask.sum().item()) / n, 5),
                 check_detail="every bit vs torch on the raw codes; first 2^20 rows vs the oracle")]
+
+
+def leg_page_lists(ips, capi, dev):
+    """The page loop of the scanner inside the launches (ips_chunk_*): configs[4]'s conjunction and
+    configs[3]'s IN scan + gather over SEPARATE page buffers per column, 2^20-row pages and pages whose
+    ends differ between the columns (every boundary inside a bitmap word), against the contiguous call."""
+    out = []
+    q6 = ips.q6
+    n = q6.ROWS
+
+    def chunk_of(vals, w, rows):
+        pages, pos = [], 0
+        while pos < vals.numel():
+            m = min(rows, vals.numel() - pos)
+            pages.append((capi.fle_encode(vals[pos:pos + m].clone(), w), m, w))
+            pos += m
+        return capi.Chunk(pages)
+    codes = [q6.codes_gpu(capi, c, n, device=dev) for c in range(3)]
+    encs = [capi.fle_encode(codes[c], q6.COLUMNS[c][3]) for c in range(3)]
+    nodes, cols = q6.program(capi, encs)
+    ref = capi.eval_program(nodes, cols, n)
+    t_c, _ = time_launches(lambda: capi.eval_program(nodes, cols, n, bitmap=ref))
+    del encs, cols
+    bm = torch.empty_like(ref)
+    for label, sizes in (("573 pages of 2^20 rows per column", (1 << 20,) * 3),
+                         ("pages of 2^20 / 2^20 - 37 / 700,001 rows (page ends differ between the columns)",
+                          (1 << 20, (1 << 20) - 37, 700001))):
+        chunks = [chunk_of(codes[c], q6.COLUMNS[c][3], sizes[c]) for c in range(3)]
+        tmed, tmin = time_launches(lambda: capi.eval_program_chunks(nodes, chunks, bitmap=bm))
+        out.append(rec(f"configs[4] Q6 conjunction over page lists, {label}", n, q6.algorithmic_bytes(n), tmed, tmin,
+                       bool(torch.equal(bm, ref)), vs_contiguous=round(tmed / t_c, 3),
+                       launches_per_step=3))
+        for ch in chunks:
+            ch.close()
+        del chunks
+    del codes, ref, bm
+    torch.cuda.empty_cache()
+    n = 1 << 28
+    W = n // 64
+    rng = np.random.default_rng(4)
+    D, K, bw = 4096, 16, 12
+    dict_vals = np.sort(rng.choice(np.arange(-2 ** 30, 2 ** 30, 7), D, replace=False)).astype(np.int32)
+    codes = ((capi.synth_u32(ips.synth.SEED_DICT, n, 32, device=dev).to(torch.int64) & 0xFFFFFFFF) % D).to(torch.int32)
+    enc = capi.fle_encode(codes, bw)
+    dd = capi.Dict(dict_vals.view(np.uint8), capi.T_INT32)
+    present = rng.choice(D, K // 2, replace=False)
+    lits = np.concatenate([dict_vals[present], dict_vals[present] + 1]).astype(np.int32)
+    res = {}
+
+    def f():
+        res["r"] = dd.scan(enc, n, bw, capi.OP_IN, lits)
+    t_c, _ = time_launches(f, reps=6)
+    ref_bm = res["r"][0].clone()
+    n_sel = int(res["r"][2].to(torch.int64).sum().item())
+    del res, enc
+    for label, rows in (("256 pages of 2^20 rows", 1 << 20), ("257 pages of 2^20 - 37 rows", (1 << 20) - 37)):
+        chunk = chunk_of(codes, bw, rows)
+        outs = chunk.alloc_outputs()
+        tmed, tmin = time_launches(lambda: chunk.dict_scan(dd, capi.OP_IN, lits, outputs=outs), reps=6)
+        ok = torch.equal(outs[0][:W], ref_bm) and int(outs[2][:chunk.n_batches].to(torch.int64).sum().item()) == n_sel
+        out.append(rec(f"configs[3] dictionary int32 D=4096 w=12 IN K=16 scan+gather over a page list, {label}", n,
+                       bw * 8 * W + 8 * W + 4 * n_sel + D * 4, tmed, tmin, bool(ok), vs_contiguous=round(tmed / t_c, 3)))
+        chunk.close()
+        del outs
+    dd.close()
+    return out
 
 
 def leg_h2d(capi, dev, enc, n, bw, c, outputs, hbm_rows_per_s):
@@ -613,7 +679,7 @@ def main():
         for leg in (lambda: leg_widths(ips, capi, dev, n), lambda: leg_plain_twin(ips, capi, dev, n),
                     lambda: leg_config2(ips, capi, dev, n),
                     lambda: leg_config3(ips, capi, dev, n), lambda: leg_nullable(capi, dev, n),
-                    lambda: leg_q6_single(ips, capi, dev, O)):
+                    lambda: leg_q6_single(ips, capi, dev, O), lambda: leg_page_lists(ips, capi, dev)):
             try:
                 configs += leg()
             except Exception as ex:

@@ -44,7 +44,7 @@ SYMBOLS = [
     "ips_select_nullable_workspace_bytes", "ips_dict_select_nullable",
     "ips_dict_translate", "ips_dict_pred", "ips_dict_decode", "ips_dict_scan", "ips_dict_select",
     "ips_plain_stride", "ips_plain_pred", "ips_plain_scan", "ips_plain_select",
-    "ips_bitmap_and", "ips_bitmap_or", "ips_bitmap_fill", "ips_bitmap_count",
+    "ips_bitmap_and", "ips_bitmap_or", "ips_bitmap_fill", "ips_bitmap_count", "ips_bitmap_batch_counts",
     "ips_expand_workspace_bytes", "ips_bitmap_expand",
     "ips_eval_program", "ips_set_program_strategy", "ips_synth_splitmix_u32",
     "ips_chunk_open", "ips_chunk_close", "ips_chunk_num_rows", "ips_chunk_num_batches", "ips_chunk_num_pages",
@@ -389,12 +389,14 @@ def select_nullable(dict_, def_levels, def_bw, max_def, n_rows, codes_enc, n_dat
                      dtype=torch.uint8, device=dev)
     dense = torch.empty(max(n_data_rows, 16), dtype=torch.int32 if dict_ is None else TORCH_SLOT[dict_.type], device=dev)
     flags = torch.empty(max(_words(n_rows), 2), dtype=torch.int64, device=dev)
-    counts = torch.zeros(2, dtype=torch.int64, device=dev)
+    counts = torch.zeros(3, dtype=torch.int64, device=dev)
     _ck(lib().ips_dict_select_nullable(dict_.h if dict_ is not None else None, _ptr(def_levels), def_bw, max_def,
                                        C.c_int64(n_rows), _ptr(codes_enc), C.c_int64(n_data_rows), bw,
                                        _ptr(selection), _ptr(dense), _ptr(flags), _ptr(counts), _ptr(ws),
                                        _stream(stream)))
-    n_sel, n_val = (int(x) for x in counts.cpu().tolist())
+    n_sel, n_val, bad = (int(x) for x in counts.cpu().tolist())
+    if bad:
+        raise IpsError(6, "a selected code lies outside the dictionary (IPS_ERR_BAD_INDEX)")
     return dense[:n_val], flags[:_words(max(n_sel, 1))], n_sel, n_val
 
 
@@ -459,6 +461,12 @@ def bitmap_count(a, n_rows, stream=None):
     cnt = torch.zeros(1, dtype=torch.int64, device=a.device)
     _ck(lib().ips_bitmap_count(_ptr(a), C.c_int64(n_rows), _ptr(cnt), _stream(stream)))
     return int(cnt.item())
+
+
+def bitmap_batch_counts(a, n_rows, stream=None):
+    counts = torch.empty(max(n_batches(n_rows), 1), dtype=torch.int32, device=a.device)
+    _ck(lib().ips_bitmap_batch_counts(_ptr(a), C.c_int64(n_rows), _ptr(counts), _stream(stream)))
+    return counts[:n_batches(n_rows)]
 
 
 def bitmap_compress(mask, src, n_rows, stream=None):

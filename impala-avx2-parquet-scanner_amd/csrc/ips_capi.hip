@@ -111,6 +111,7 @@ IPS_DECL_PARTS(a) IPS_DECL_PARTS(b) IPS_DECL_PARTS(c) IPS_DECL_PARTS(d)
 ips_status launch_bitmap_binop(int op, uint64_t* a, const uint64_t* b, int64_t n_words, hipStream_t s);
 ips_status launch_bitmap_fill(uint64_t* a, int64_t n_rows, int value, hipStream_t s);
 ips_status launch_bitmap_count(const uint64_t* a, int64_t n_rows, int64_t* count, hipStream_t s);
+ips_status launch_bitmap_batch_counts(const uint64_t* bitmap, int64_t n_rows, uint32_t* counts, hipStream_t s);
 ips_status launch_bitmap_expand(const uint64_t* root, const uint64_t* sub, int64_t n_rows,
                                 uint64_t* out, void* workspace, hipStream_t s);
 ips_status launch_batches_compact(const void* batch_values, const uint32_t* counts,
@@ -904,10 +905,8 @@ ips_status ips_dict_select_nullable(const ips_dict* dict, const void* d_def_leve
   IPS_REQUIRE(n_rows == 0 || (d_selection && aligned16(d_selection) && d_dense_values && aligned16(d_dense_values)),
               "ips_dict_select_nullable: NULL or misaligned argument");
   hipStream_t s = S(stream);
-  if (n_rows == 0) {
-    IPS_HIP_TRY(hipMemsetAsync(d_counts, 0, 16, s));
-    return IPS_OK;
-  }
+  IPS_HIP_TRY(hipMemsetAsync(d_counts, 0, 24, s));  // (also the bad-index flag, set by the kernels)
+  if (n_rows == 0) return IPS_OK;
   const int vw = dict ? dict->slot : 4;
   const SelNullWs w = sel_null_ws(d_workspace, n_rows, n_data_rows, vw);
   NullableWs nws;
@@ -936,6 +935,7 @@ ips_status ips_dict_select_nullable(const ips_dict* dict, const void* d_def_leve
       a.c_rs = w.rank_rs;
       a.flags = reinterpret_cast<unsigned long long*>(d_nonnull_flags);
       a.n_selected = d_counts;
+      a.bad_index = d_counts + 2;
       a.n_rows = n_rows;
       a.root_kind = root_kind;
       st = launch_fle_selnull(bit_width, dict ? dict->slot : 0, reinterpret_cast<const uint64_t*>(d_codes_enc), n_data,
@@ -958,7 +958,8 @@ ips_status ips_dict_select_nullable(const ips_dict* dict, const void* d_def_leve
     st = launch_fle_scan(bit_width, kScanGivenBitmap, dict ? dict->slot : 0,
                          reinterpret_cast<const uint64_t*>(d_codes_enc), n_data, args, nullptr,
                          reinterpret_cast<const uint32_t*>(w.data_sel), w.batch_values, w.batch_counts,
-                         dict ? dict->d_entries : nullptr, dict ? (uint32_t)dict->n : 0u, nullptr, s);
+                         dict ? dict->d_entries : nullptr, dict ? (uint32_t)dict->n : 0u,
+                         reinterpret_cast<int32_t*>(d_counts + 2), s);
     if (st != IPS_OK) return st;
     st = launch_batches_compact(w.batch_values, w.batch_counts, n_batches_of(n_data), vw, d_dense_values,
                                 d_counts + 1, w.compact_ws, s);
@@ -1065,6 +1066,10 @@ ips_status ips_bitmap_fill(uint64_t* d_a, int64_t n_rows, int value, ips_stream 
 ips_status ips_bitmap_count(const uint64_t* d_a, int64_t n_rows, int64_t* d_count, ips_stream stream) {
   IPS_REQUIRE(n_rows >= 0 && d_count && (n_rows == 0 || d_a), "ips_bitmap_count: bad argument");
   return launch_bitmap_count(d_a, n_rows, d_count, S(stream));
+}
+ips_status ips_bitmap_batch_counts(const uint64_t* d_a, int64_t n_rows, uint32_t* d_batch_counts, ips_stream stream) {
+  IPS_REQUIRE(n_rows >= 0 && (n_rows == 0 || (d_a && d_batch_counts)), "ips_bitmap_batch_counts: bad argument");
+  return launch_bitmap_batch_counts(d_a, n_rows, d_batch_counts, S(stream));
 }
 size_t ips_expand_workspace_bytes(int64_t n_rows) {  // shared by ips_bitmap_expand and ips_bitmap_compress
   const size_t a = scan_workspace_bytes((n_rows + 63) / 64), b = rank_workspace_bytes(n_rows < 0 ? 0 : n_rows);

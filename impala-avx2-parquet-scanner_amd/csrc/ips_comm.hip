@@ -85,6 +85,8 @@ struct ips_comm {
 
 extern "C" {
 
+ips_status ips_comm_join(ips_comm* comm, ips_stream stream);
+
 ips_status ips_comm_unique_id(void* id_bytes, int len) {
   IPS_REQUIRE(id_bytes && len >= IPS_COMM_ID_BYTES, "ips_comm_unique_id: need %d bytes", IPS_COMM_ID_BYTES);
   Rccl* r = rccl();
@@ -168,6 +170,13 @@ ips_status ips_fle_scan_allgather(ips_comm* comm, const void* d_enc, int64_t n_r
   // ncclAllGather call takes the host 10-20 us, and issued between the scans it left the GPU idle
   // between chunk kernels
   IPS_REQUIRE(n_chunks <= 64, "ips_fle_scan_allgather: at most 64 chunks per step");
+  // the gathers of an earlier step may still be reading d_local_bitmap: the scans of this step wait
+  // for whatever the communicator's stream has been given so far (what ips_comm_join does), so the
+  // buffers can be reused step after step without a caller-side contract
+  {
+    ips_status jst = ips_comm_join(comm, stream);
+    if (jst != IPS_OK) return jst;
+  }
   hipEvent_t done[64];
   for (int i = 0; i < n_chunks; ++i) {
     ips_status st = ips_fle_scan(enc + (size_t)i * (size_t)words_c * (size_t)bit_width * 8, rows_c, bit_width,

@@ -999,6 +999,7 @@ struct SelNullArgs {
   const uint32_t* c_rs;
   unsigned long long* flags;  // one NOT-NULL bit per selected row, cleared by the counting pass
   int64_t* n_selected;        // popcount of the selection
+  int64_t* bad_index;         // set non-zero when a selected code lies outside the dictionary
   int64_t n_rows;
   int32_t root_kind;
 };
@@ -1239,6 +1240,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_select_nul
         for (int b = 0; b < W; ++b) val |= ((pl[2 * b] >> sh) & 1u) << b;
         if (G == 0) dst[win0 + e] = (GT)val;
         else if (val < dict_entries) dst[win0 + e] = dict[val];
+        else if (a.bad_index) *a.bad_index = 1;  // DictDecoder::GetValue returns false (dict-encoding.h:316)
       }
       wave_lds_fence();  // the list is rewritten by the next window, the image by the next sub-tile
     }

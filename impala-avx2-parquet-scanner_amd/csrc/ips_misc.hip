@@ -117,6 +117,34 @@ ips_status launch_bitmap_count(const uint64_t* a, int64_t n_rows, int64_t* count
   return IPS_OK;
 }
 
+// The selected rows of every 2048-row batch of a selection (what a fused scan writes next to its
+// values): one wave per batch, lane l the dword l of the batch's 32 words.
+__global__ __launch_bounds__(256) void bitmap_batch_counts_kernel(const uint32_t* __restrict__ bitmap32,
+                                                                  int64_t n_rows, uint32_t* __restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n_batches = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int64_t dwords = 2 * ((n_rows + 63) / 64);
+  for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < n_batches; b += (int64_t)gridDim.x * 4) {
+    const int64_t d = b * 64 + lane;
+    uint32_t w = d < dwords ? bitmap32[d] : 0u;
+    const int64_t valid = n_rows - d * 32;
+    if (valid < 32) w = valid <= 0 ? 0u : (w & ((1u << valid) - 1u));
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)__builtin_popcount(w)), 63);
+    if (lane == 0) counts[b] = total;
+  }
+}
+
+ips_status launch_bitmap_batch_counts(const uint64_t* bitmap, int64_t n_rows, uint32_t* counts, hipStream_t s) {
+  if (n_rows <= 0) return IPS_OK;
+  const int64_t n_batches = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  int grid = small_grid((n_batches + 3) / 4, 1);
+  if (grid > device_cus() * 16) grid = device_cus() * 16;
+  hipLaunchKernelGGL(bitmap_batch_counts_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(bitmap),
+                     n_rows, counts);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
 // =============================================================================================
 // Device-wide exclusive scan of small per-item counts (three launches), shared by
 //  - IntersectBitset expand: items = bitmap words, count = popcount      (scanner.cc:326-331)

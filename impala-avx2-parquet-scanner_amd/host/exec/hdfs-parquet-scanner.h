@@ -42,9 +42,27 @@ class HdfsParquetScanner {
         return *keep.back();
       }
       ips::DeviceBuffer counts;  // batch counts of the selection (shared by all REQUIRED columns)
+      std::vector<const int64_t*> bad_index;  // device flags: a selected code outside its dictionary
     };
     virtual bool SelectInto(int64_t num_rows, const uint64_t* d_selection, ips_tuple_column* col,
                             Materialised* m) = 0;
+    // facade extra (EvalSimplePredicatesChunks): the whole column chunk -- the current page and the
+    // queued ones -- as an ips_chunk; 'keep' owns the device copies of the queued pages
+    struct ChunkHolder {
+      ips_chunk* chunk = nullptr;
+      std::vector<std::unique_ptr<ips::DeviceBuffer>> keep;
+      ChunkHolder() {}
+      ChunkHolder(const ChunkHolder&) = delete;
+      ChunkHolder& operator=(const ChunkHolder&) = delete;
+      ~ChunkHolder() { if (chunk) ips_chunk_close(chunk); }
+      const void* upload(const void* h, size_t bytes) {
+        keep.emplace_back(new ips::DeviceBuffer());
+        return keep.back()->upload(h, bytes) ? keep.back()->get() : nullptr;
+      }
+    };
+    virtual bool OpenChunk(ChunkHolder* h) = 0;
+    // rows of the current page (DataPageHeader.num_values): what the device buffers of the page hold
+    int64_t page_rows() const { return page_rows_; }
     int64_t num_buffered_values() const { return num_buffered_values_; }
     void consume(int64_t n) { num_buffered_values_ -= n; }
     int max_def_level() const { return max_def_level_; }
@@ -72,6 +90,7 @@ class HdfsParquetScanner {
    protected:
     virtual bool InitDataPage(uint8_t* data, int len, int64_t num_values) = 0;
     int64_t num_buffered_values_ = 0;
+    int64_t page_rows_ = 0;
     int max_def_level_ = 0;
     std::vector<PendingPage> pending_pages_;
     // decompressed pages / the dictionary of a chunk read through AddColumnChunk (the reference's
@@ -200,7 +219,8 @@ class HdfsParquetScanner {
         const int64_t n_data = dict_decoder_->codes()->rows_in_buffer();
         ips::DeviceBuffer& dense = m->add((size_t)std::max<int64_t>(n_data, 16) * vw);
         ips::DeviceBuffer& flags = m->add((size_t)((num_rows + 63) / 64 + 2) * 8);
-        ips::DeviceBuffer& cnt = m->add(16);
+        ips::DeviceBuffer& cnt = m->add(32);
+        m->bad_index.push_back(cnt.as<int64_t>() + 2);
         ips::DeviceBuffer& ws = m->add(ips_select_nullable_workspace_bytes(num_rows, n_data, vw));
         if (!ips::ok(ips_dict_select_nullable(dict_decoder_->handle(), fle_def_levels_->device_blocks(),
                                               fle_def_levels_->bit_width(), max_def_level_, num_rows,
@@ -229,6 +249,68 @@ class HdfsParquetScanner {
       return true;
     }
 
+    // the current page (already resident) followed by the queued ones (uploaded here)
+    virtual bool OpenChunk(ChunkHolder* h) {
+      std::vector<ips_chunk_page> pages;
+      const int stride = ips_plain_stride(IpsTypeOf<T>::value);
+      if (dict_decoder_) {
+        if (max_def_level_ > 1) return false;  // flat schemas only (hdfs-parquet-scanner.cc:338-345)
+        ips_chunk_page pg;
+        memset(&pg, 0, sizeof(pg));
+        pg.d_data = dict_decoder_->codes()->device_blocks();
+        pg.n_rows = page_rows_;
+        pg.bit_width = dict_decoder_->code_bit_width();
+        if (max_def_level_ > 0) {
+          if (!fle_def_levels_ || !fle_def_levels_->usable()) return false;
+          pg.d_def_levels = fle_def_levels_->device_blocks();
+          pg.n_data_rows = dict_decoder_->codes()->rows_in_buffer();
+        }
+        if (page_rows_ > 0) pages.push_back(pg);
+        for (const PendingPage& pp : pending_pages_) {
+          uint8_t *def = nullptr, *codes = nullptr;
+          int n_def_bytes = 0, codes_len = 0;
+          if (!SplitDataPage(pp.data, pp.len, max_def_level_, &def, &n_def_bytes, &codes, &codes_len) ||
+              parquet::CheckDictDataPage(def, n_def_bytes, codes, codes_len, max_def_level_, pp.num_values))
+            return ips::ok(IPS_ERR_INVALID_ARG, "OpenChunk: truncated or corrupt data page");
+          if (pp.num_values == 0) continue;
+          memset(&pg, 0, sizeof(pg));
+          pg.n_rows = pp.num_values;
+          pg.bit_width = codes[0];
+          const int64_t blocks = (codes_len - 1) / (8 * pg.bit_width);
+          pg.d_data = h->upload(codes + 1, (size_t)(blocks * 8 * pg.bit_width));
+          if (!pg.d_data) return false;
+          if (max_def_level_ > 0) {
+            pg.d_def_levels = h->upload(def, (size_t)(((pp.num_values + 63) / 64) * 8));
+            if (!pg.d_def_levels) return false;
+            pg.n_data_rows = blocks * 64;
+          }
+          pages.push_back(pg);
+        }
+        return ips::ok(ips_chunk_open(pages.data(), (int)pages.size(), IPS_COL_FLE, IpsTypeOf<T>::value, max_def_level_,
+                                      &h->chunk), "ips_chunk_open");
+      }
+      if (max_def_level_ > 0) return false;  // the PLAIN branch has no NULL handling (.cc:346-348)
+      ips_chunk_page pg;
+      memset(&pg, 0, sizeof(pg));
+      if (plain_rows_ > 0) {
+        if (!EnsurePlainResident()) return false;
+        pg.d_data = plain_dev_.get();
+        pg.n_rows = plain_rows_;
+        pages.push_back(pg);
+      }
+      for (const PendingPage& pp : pending_pages_) {
+        if (pp.num_values == 0) continue;
+        if ((int64_t)pp.len < pp.num_values * stride) return ips::ok(IPS_ERR_INVALID_ARG, "OpenChunk: truncated PLAIN page");
+        memset(&pg, 0, sizeof(pg));
+        pg.n_rows = pp.num_values;
+        pg.d_data = h->upload(pp.data, (size_t)(pp.num_values * stride));
+        if (!pg.d_data) return false;
+        pages.push_back(pg);
+      }
+      return ips::ok(ips_chunk_open(pages.data(), (int)pages.size(), IPS_COL_PLAIN, IpsTypeOf<T>::value, 0, &h->chunk),
+                     "ips_chunk_open");
+    }
+
    protected:
     // [int32 n_def_bytes][def levels]? [uint8 width][codes] for dictionary columns, raw slots for
     // PLAIN ones; the dictionary stays (one dictionary page per column chunk)
@@ -237,9 +319,11 @@ class HdfsParquetScanner {
       if (dict_decoder_) {
         uint8_t *def = nullptr, *codes = nullptr;
         int n_def_bytes = 0, codes_len = 0;
-        if (!SplitDataPage(data, len, max_def_level_, &def, &n_def_bytes, &codes, &codes_len)) {
+        page_rows_ = num_values;
+        if (!SplitDataPage(data, len, max_def_level_, &def, &n_def_bytes, &codes, &codes_len) ||
+            parquet::CheckDictDataPage(def, n_def_bytes, codes, codes_len, max_def_level_, num_values)) {
           ips::ok(IPS_ERR_INVALID_ARG, "InitDataPage: truncated or corrupt data page");
-          num_buffered_values_ = 0;
+          num_buffered_values_ = page_rows_ = 0;
           return false;
         }
         if (max_def_level_ > 0)  // .cc:882-901
@@ -248,7 +332,7 @@ class HdfsParquetScanner {
         return true;
       }
       data_ = plain_begin_ = data;
-      plain_rows_ = num_values;
+      plain_rows_ = page_rows_ = num_values;
       T dummy;
       data_end_ = data + num_values * ParquetPlainEncoder::ByteSize(dummy);
       plain_dev_.release();
@@ -300,12 +384,13 @@ class HdfsParquetScanner {
     uint8_t *def = nullptr, *codes = nullptr;
     int n_def_bytes = 0, codes_len = 0;
     if (!BaseColumnReader::SplitDataPage(data_page, data_len, max_def_level, &def, &n_def_bytes, &codes,
-                                         &codes_len)) {
+                                         &codes_len) ||
+        parquet::CheckDictDataPage(def, n_def_bytes, codes, codes_len, max_def_level, num_values)) {
       ips::ok(IPS_ERR_INVALID_ARG, "AddDictionaryColumn: truncated or corrupt data page");
       return -1;
     }
     auto* r = new ColumnReader<T>();
-    r->num_buffered_values_ = num_values;
+    r->num_buffered_values_ = r->page_rows_ = num_values;
     r->max_def_level_ = max_def_level;
     if (max_def_level > 0)  // .cc:882-901
       r->fle_def_levels_.reset(new FleDecoder(def, n_def_bytes, BitUtil::Log2((uint64_t)max_def_level + 1)));
@@ -318,7 +403,7 @@ class HdfsParquetScanner {
   template <typename T>
   int AddPlainColumn(uint8_t* page, int64_t num_values) {
     auto* r = new ColumnReader<T>();
-    r->num_buffered_values_ = num_values;
+    r->num_buffered_values_ = r->page_rows_ = num_values;
     r->data_ = r->plain_begin_ = page;
     r->plain_rows_ = num_values;
     T dummy;
@@ -365,11 +450,22 @@ class HdfsParquetScanner {
     } else {
       // PLAIN pages: the values follow the level bytes (data_ += num_definition_bytes, .cc:916-917);
       // the PLAIN branch of the predicates ignores the levels (quirk Q3)
+      // (an OPTIONAL PLAIN page stores its non-NULL values only; with a NULL in it the vectorised
+      // PLAIN path, which never looks at the levels (.cc:346-348, quirk Q3), would read other rows)
+      bool has_nulls = false;
       auto values_of = [&](const DataPage& pg, uint8_t** v) -> bool {
-        return parquet::PlainPageValues(pg.bytes->data(), (int64_t)pg.bytes->size(), max_def_level, pg.num_values,
-                                        ips_plain_stride(IpsTypeOf<T>::value), v);
+        int64_t stored = 0;
+        if (!parquet::PlainPageValues(pg.bytes->data(), (int64_t)pg.bytes->size(), max_def_level, pg.num_values,
+                                      ips_plain_stride(IpsTypeOf<T>::value), v, &stored))
+          return false;
+        has_nulls = has_nulls || stored != pg.num_values;
+        return true;
       };
       uint8_t* v = nullptr;
+      for (size_t i = 0; i < data_pages.size(); ++i)
+        if (!values_of(data_pages[i], &v)) return fail("truncated PLAIN data page");
+      if (has_nulls)
+        return fail("OPTIONAL PLAIN pages with NULLs need the row-at-a-time path (the vectorised PLAIN branch ignores definition levels)");
       if (!values_of(data_pages[0], &v)) return fail("truncated PLAIN data page");
       idx = AddPlainColumn<T>(v, data_pages[0].num_values);
       for (size_t i = 1; i < data_pages.size(); ++i) {
@@ -438,7 +534,18 @@ class HdfsParquetScanner {
   // facade extra: the whole conjunct list over all rows of the pages in one ips_eval_program
   // call (REQUIRED and OPTIONAL dictionary columns, PLAIN columns).  bitmap_words:
   // ceil(num_rows/64) LSB-first words.
+  // the fused calls hand num_rows straight to the device: never more than every column's current
+  // page holds (a page header may lie about num_values; the per-batch path is bounded by
+  // append_bits, the page checks of InitDataPage bound what was uploaded)
+  bool RowsResident(int64_t num_rows) const {
+    if (num_rows < 0) return false;
+    for (auto& c : column_readers_)
+      if (num_rows > c->page_rows()) return ips::ok(IPS_ERR_INVALID_ARG, "fused call: num_rows exceeds the rows of a column's current page");
+    return true;
+  }
+
   bool EvalSimplePredicatesFused(int64_t num_rows, std::vector<uint64_t>* bitmap_words) {
+    if (!RowsResident(num_rows)) return false;
     lower_cols_.clear();
     std::vector<ips_node> program;
     for (size_t i = 0; i < simple_predicates_.size(); ++i) {
@@ -459,6 +566,45 @@ class HdfsParquetScanner {
            bm.download(bitmap_words->data(), bitmap_words->size() * 8);
   }
 
+  // facade extra: the conjunct list over EVERY page of the column chunks -- each reader's current
+  // page and the ones queued behind it (AddColumnChunk / AddDataPage) -- in one
+  // ips_eval_program_chunks call: the page loop of EvalSimplePredicates (.cc:1837-1855, batches cut at
+  // every column's page end) runs inside the launches, pages of different columns need not align.
+  // *num_rows = rows of the chunks; bitmap_words: ceil(rows / 64) LSB-first words.
+  bool EvalSimplePredicatesChunks(std::vector<uint64_t>* bitmap_words, int64_t* num_rows) {
+    lower_cols_.clear();
+    chunk_readers_.clear();
+    lower_chunks_ = true;
+    std::vector<ips_node> program;
+    bool lowered = true;
+    for (size_t i = 0; i < simple_predicates_.size() && lowered; ++i) {
+      lowered = simple_predicates_[i]->Lower(this, &program);
+      if (lowered && i > 0) { ips_node n; memset(&n, 0, sizeof(n)); n.kind = IPS_NODE_AND; program.push_back(n); }
+    }
+    lower_chunks_ = false;
+    if (!lowered || program.empty()) return false;
+    std::vector<std::unique_ptr<BaseColumnReader::ChunkHolder>> holders;
+    std::vector<const ips_chunk*> chunks;
+    for (int idx : chunk_readers_) {
+      holders.emplace_back(new BaseColumnReader::ChunkHolder());
+      if (!column_readers_[(size_t)idx]->OpenChunk(holders.back().get())) return false;
+      chunks.push_back(holders.back()->chunk);
+    }
+    const int64_t n = ips_chunk_num_rows(chunks[0]);
+    for (const ips_chunk* c : chunks)
+      if (ips_chunk_num_rows(c) != n) return ips::ok(IPS_ERR_INVALID_ARG, "EvalSimplePredicatesChunks: the column chunks hold different row counts");
+    *num_rows = n;
+    bitmap_words->assign((size_t)((n + 63) / 64), 0);
+    if (n == 0) return true;
+    ips::DeviceBuffer bm(bitmap_words->size() * 8);
+    const size_t ws_bytes = ips_chunk_program_workspace_bytes(program.data(), (int)program.size(), chunks.data(), (int)chunks.size());
+    if (ws_bytes > 0 && !program_workspace_.resize(ws_bytes)) return false;
+    return ips::ok(ips_eval_program_chunks(program.data(), (int)program.size(), chunks.data(), (int)chunks.size(),
+                                           bm.as<uint64_t>(), ws_bytes ? program_workspace_.get() : nullptr, nullptr),
+                   "ips_eval_program_chunks") &&
+           bm.download(bitmap_words->data(), bitmap_words->size() * 8);
+  }
+
   // facade extra: AssembleRows' vector path (.cc:1101-1182) for num_rows rows of the current pages
   // in a handful of launches -- the conjunct list (ips_eval_program), every slot's late
   // materialisation against the resulting bitmap, and the row-major tuples (ips_assemble_tuples:
@@ -473,7 +619,7 @@ class HdfsParquetScanner {
   bool AssembleRowsFused(int64_t num_rows, int tuple_size, const uint8_t* template_tuple,
                          const std::vector<SlotDesc>& slots, std::vector<uint8_t>* tuples,
                          int64_t* num_tuples) {
-    if (slots.empty() || slots.size() > IPS_TUPLE_MAX_COLS) return false;
+    if (slots.empty() || slots.size() > IPS_TUPLE_MAX_COLS || !RowsResident(num_rows)) return false;
     std::vector<uint64_t> words;
     lower_cols_.clear();
     std::vector<ips_node> program;
@@ -508,13 +654,9 @@ class HdfsParquetScanner {
     }
     if (!mat.counts.get()) {  // only OPTIONAL slots: the batch counts come from the bitmap itself
       const int64_t nb = (num_rows + IPS_BATCH_ROWS - 1) / IPS_BATCH_ROWS;
-      ips::DeviceBuffer dummy((size_t)nb * IPS_BATCH_ROWS * 4);
-      if (!mat.counts.resize((size_t)nb * 4)) return false;
-      // a width-1 column of zeros selected by the bitmap yields exactly the counts
-      ips::DeviceBuffer zeros((size_t)ips_fle_encoded_bytes(num_rows, 1) + 16);
-      if (!ips::ok(ips_memset(zeros.get(), 0, zeros.size(), nullptr), "ips_memset") ||
-          !ips::ok(ips_fle_select(zeros.get(), num_rows, 1, bm.as<uint64_t>(), dummy.as<uint32_t>(),
-                                  mat.counts.as<uint32_t>(), nullptr), "ips_fle_select"))
+      if (!mat.counts.resize((size_t)nb * 4) ||
+          !ips::ok(ips_bitmap_batch_counts(bm.as<uint64_t>(), num_rows, mat.counts.as<uint32_t>(), nullptr),
+                   "ips_bitmap_batch_counts"))
         return false;
     }
     int64_t count = 0;
@@ -530,6 +672,13 @@ class HdfsParquetScanner {
       return false;
     int64_t total = 0;
     if (!d_total.download(&total, 8) || total != count) return false;
+    for (const int64_t* flag : mat.bad_index) {  // DictDecoder::GetValue returning false (dict-encoding.h:316)
+      int64_t bad = 0;
+      if (!ips::ok(ips_memcpy_d2h(&bad, flag, 8, nullptr), "ips_memcpy_d2h") ||
+          !ips::ok(ips_stream_synchronize(nullptr), "ips_stream_synchronize"))
+        return false;
+      if (bad) return ips::ok(IPS_ERR_BAD_INDEX, "AssembleRowsFused: a dictionary code outside the dictionary");
+    }
     tuples->assign((size_t)total * tuple_size, 0);
     *num_tuples = total;
     return total == 0 || d_tuples.download(tuples->data(), tuples->size());
@@ -537,8 +686,17 @@ class HdfsParquetScanner {
 
   // used by LeafOperate::Lower: returns the column slot of the program for reader idx
   bool LowerLeaf(int idx, int op, const void* lits, int n_lits, ips_node* node) {
-    if (lower_cols_.size() >= IPS_PROGRAM_MAX_COLS) return false;
     ips_column col;
+    if (lower_chunks_) {  // leaf.column = the slot of reader idx among the chunks of this evaluation
+      if (!column_readers_[(size_t)idx]->LowerLeaf(op, lits, n_lits, &col, node)) return false;
+      for (size_t i = 0; i < chunk_readers_.size(); ++i)
+        if (chunk_readers_[i] == idx) { node->column = (int)i; return true; }
+      if (chunk_readers_.size() >= IPS_PROGRAM_MAX_COLS) return false;
+      chunk_readers_.push_back(idx);
+      node->column = (int)chunk_readers_.size() - 1;
+      return true;
+    }
+    if (lower_cols_.size() >= IPS_PROGRAM_MAX_COLS) return false;
     if (!column_readers_[(size_t)idx]->LowerLeaf(op, lits, n_lits, &col, node)) return false;
     for (size_t i = 0; i < lower_cols_.size(); ++i)
       if (lower_cols_[i].d_data == col.d_data) { node->column = (int)i; return true; }
@@ -559,6 +717,8 @@ class HdfsParquetScanner {
   std::vector<SimplePredicate*> simple_predicates_;
   std::vector<SimplePredicate*> owned_;
   std::vector<ips_column> lower_cols_;
+  std::vector<int> chunk_readers_;  // EvalSimplePredicatesChunks: reader index of every chunk slot
+  bool lower_chunks_ = false;
   ips::DeviceBuffer program_workspace_;
 };
 

@@ -52,21 +52,69 @@ inline bool SplitDataPage(uint8_t* data, int len, int max_def_level, uint8_t** d
   return true;
 }
 
-// PLAIN pages: the values follow the level bytes (data_ += num_definition_bytes, .cc:916-917)
+// rows of a page whose level equals max_def_level: the values the page stores.  Levels are an FLE
+// column of width Log2(max_def_level + 1) over num_values rows (writer :387-399): value k of block b
+// is bit 63 - k of the block's words (fle-encoding.h:8338-8340).  -1: the bytes do not cover the rows.
+inline int64_t CountNonNull(const uint8_t* levels, int64_t n_bytes, int max_def_level, int64_t num_values) {
+  int w = 0;
+  for (uint64_t x = (uint64_t)max_def_level; x; x >>= 1) ++w;  // Log2(max + 1) for max >= 1
+  if (w < 1 || num_values < 0) return -1;
+  const int64_t blocks = (num_values + 63) / 64;
+  if (blocks * 8 * w > n_bytes) return -1;
+  int64_t count = 0;
+  for (int64_t b = 0; b < blocks; ++b) {
+    uint64_t eq = ~0ull;  // rows whose level equals max_def_level
+    for (int i = 0; i < w; ++i) {
+      uint64_t plane;
+      memcpy(&plane, levels + (b * w + i) * 8, 8);
+      eq &= ((uint64_t)max_def_level >> i) & 1 ? plane : ~plane;
+    }
+    const int64_t rows = num_values - b * 64;
+    if (rows < 64) eq &= ~0ull << (64 - rows);  // row k sits at bit 63 - k
+    count += __builtin_popcountll(eq);
+  }
+  return count;
+}
+
+// What AddColumnChunk's pages promise must be there before the device reads it (the reference's
+// decoders check every Get against buffer_end_guard_, fle-encoding.h:350,407; its predicates do not,
+// quirk Q7 -- a header that claims more num_values than the level or code blocks hold would send the
+// fused kernels past the device allocations).  nullptr = the page holds its rows.
+inline const char* CheckDictDataPage(const uint8_t* def_levels, int n_def_bytes, const uint8_t* codes, int codes_len,
+                                     int max_def_level, int64_t num_values) {
+  if (codes == nullptr || codes_len < 1) return "data page without a code-width byte";
+  const int bw = codes[0];
+  if (bw < 1 || bw > 32) return "code width outside 1..32";
+  int64_t data_rows = num_values;
+  if (max_def_level > 0) {
+    data_rows = CountNonNull(def_levels, n_def_bytes, max_def_level, num_values);
+    if (data_rows < 0) return "definition levels hold fewer rows than the page header states";
+  }
+  if (((data_rows + 63) / 64) * 8 * bw > (int64_t)codes_len - 1)
+    return "code blocks hold fewer rows than the page header states";
+  return nullptr;
+}
+
+// PLAIN pages: the values follow the level bytes (data_ += num_definition_bytes, .cc:916-917).  An
+// OPTIONAL page stores its non-NULL values only: *n_stored = the rows the levels say are there.
 inline bool PlainPageValues(uint8_t* data, int64_t len, int max_def_level, int64_t num_values,
-                            int value_stride, uint8_t** values) {
+                            int value_stride, uint8_t** values, int64_t* n_stored = nullptr) {
   uint8_t* p = data;
   int64_t left = len;
   if (data == nullptr || len < 0 || num_values < 0) return false;
+  int64_t stored = num_values;
   if (max_def_level > 0) {
     if (left < 4) return false;
     int32_t nb;
     memcpy(&nb, p, 4);
     if (nb < 0 || nb > left - 4) return false;
+    stored = CountNonNull(p + 4, nb, max_def_level, num_values);
+    if (stored < 0) return false;
     p += 4 + nb; left -= 4 + nb;
   }
-  if (left < num_values * value_stride) return false;
+  if (left < stored * value_stride) return false;
   *values = p;
+  if (n_stored) *n_stored = stored;
   return true;
 }
 

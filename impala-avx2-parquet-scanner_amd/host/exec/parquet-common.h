@@ -82,7 +82,11 @@ class ParquetPlainEncoder {
                    SkipBitset& out, const T* lits, int n_lits) {
     if (num_rows <= 0) return;
     const ips_type t = IpsTypeOf<T>::value;
-    ips::DeviceBuffer page, bm((size_t)((num_rows + 63) / 64) * 8);
+    // the static interface has nowhere to keep a page (the scanner's column reader does: it uploads
+    // a page once per InitDataPage and caches whole-page bitmaps, hdfs-parquet-scanner.h); the device
+    // scratch at least lives as long as the calling thread: no device allocation per call
+    static thread_local ips::DeviceBuffer page, bm;
+    if (!bm.resize((size_t)((num_rows + 63) / 64) * 8)) return;
     std::vector<uint64_t> words((size_t)((num_rows + 63) / 64), 0);
     if (page.upload(buffer, (size_t)num_rows * ips_plain_stride(t)) &&
         ips::ok(ips_plain_pred(page.get(), num_rows, t, op, lits, n_lits,

@@ -427,6 +427,28 @@ static void TestScannerMultiPage() {
     // PLAIN leaves use the reference operand order (literal OP x): "gt 1500" means 1500 > x
     return c0[(size_t)i] < 350 && ((!c1_null[(size_t)i] && c1[(size_t)i] >= 10) || 1500 > c2[(size_t)i]);
   };
+  // the same pages through the page-list evaluation: every page of the three chunks in one
+  // ips_eval_program_chunks call, page ends at 3000 / 8000, 4000 and 7000 rows
+  {
+    HdfsParquetScanner s2;
+    s2.AddDictionaryColumn<int32_t>(d0.data(), e0.dict_encoded_size(), p0[0].data(), (int)p0[0].size(), b0[1] - b0[0]);
+    s2.AddDictionaryColumn<int32_t>(d1.data(), e1.dict_encoded_size(), p1[0].data(), (int)p1[0].size(), b1[1] - b1[0], 1);
+    s2.AddPlainColumn<int32_t>(plain.data(), b2[1]);
+    for (int k = 1; k < 3; ++k) s2.AddDataPage(0, p0[(size_t)k].data(), (int)p0[(size_t)k].size(), b0[k + 1] - b0[k]);
+    s2.AddDataPage(1, p1[1].data(), (int)p1[1].size(), b1[2] - b1[1]);
+    s2.AddDataPage(2, plain.data() + (size_t)b2[1] * 4, (n - b2[1]) * 4, n - b2[1]);
+    std::vector<SimplePredicate*> roots2;
+    CHECK(CreateSimplePredicates(&s2, ctxs, &roots2));
+    for (SimplePredicate* r : roots2) s2.AddSimplePredicate(r);
+    std::vector<uint64_t> words;
+    int64_t rows = 0;
+    CHECK(s2.EvalSimplePredicatesChunks(&words, &rows));
+    CHECK(rows == n && (int64_t)words.size() == (n + 63) / 64);
+    int64_t wrong = 0;
+    for (int i = 0; i < n; ++i) wrong += (((words[(size_t)i >> 6] >> (i & 63)) & 1) != 0) != expect(i);
+    CHECK(wrong == 0);
+    CHECK((words.back() >> (n & 63)) == 0);  // bits behind the last row are zero
+  }
   // rows left in each column's current page bound every batch
   const int cuts[] = {3000, 4000, 7000, 8000, n};
   int64_t row = 0, selected = 0;
@@ -564,6 +586,23 @@ static void TestTruncatedPages() {
   CHECK(s.AddDictionaryColumn<int32_t>(dict.data(), e.dict_encoded_size(), page.data(), (int)page.size(), 200, 1) == -1);  // negative
   memcpy(page.data(), &n_def, 4);
   CHECK(s.AddDictionaryColumn<int32_t>(dict.data(), e.dict_encoded_size(), page.data(), 36, 200, 1) == -1);     // no width byte left
+  // a page header that claims more rows than the level / code blocks hold: refused before
+  // anything is uploaded -- the fused kernels would read past the device allocations
+  CHECK(s.AddDictionaryColumn<int32_t>(dict.data(), e.dict_encoded_size(), page.data(), (int)page.size(), 257, 1) == -1);     // levels cover 256 rows
+  CHECK(s.AddDictionaryColumn<int32_t>(dict.data(), e.dict_encoded_size(), page.data(), (int)page.size(), 256, 1) >= 0);      // (whole blocks: 256 row slots exist)
+  CHECK(s.AddDictionaryColumn<int32_t>(dict.data(), e.dict_encoded_size(), data.data(), len, 100000, 0) == -1);               // REQUIRED: codes for 200 rows
+  CHECK(s.AddDictionaryColumn<int32_t>(dict.data(), e.dict_encoded_size(), data.data(), len, 200, 0) >= 0);
+  {
+    HdfsParquetScanner lying;
+    CHECK(lying.AddDictionaryColumn<int32_t>(dict.data(), e.dict_encoded_size(), data.data(), len, 200, 0) == 0);
+    lying.AddSimplePredicate(lying.Own(new LtOperate<int32_t>(0, 5)));
+    std::vector<uint64_t> words;
+    CHECK(!lying.EvalSimplePredicatesFused(100000, &words));   // more rows than the page holds
+    CHECK(lying.EvalSimplePredicatesFused(200, &words));
+    lying.AddDataPage(0, data.data(), len, 100000);            // a queued page that lies: the chunk is refused
+    int64_t rows = 0;
+    CHECK(!lying.EvalSimplePredicatesChunks(&words, &rows));
+  }
   page[36] = 77;
   CHECK(s.AddDictionaryColumn<int32_t>(dict.data(), e.dict_encoded_size(), page.data(), (int)page.size(), 200, 1) == -1);  // width 77
   CHECK(ips::sticky_status() == IPS_ERR_INVALID_ARG);
@@ -606,6 +645,15 @@ static void TestColumnChunkStream() {
     scanner.AddSimplePredicate(p0);
     scanner.AddSimplePredicate(p1);
     auto expect = [&](int i) { return c0[i] >= -100 && c0[i] < 350 && !c1_null[i] && c1[i] <= 150 * 1000003ll; };
+    {  // the whole chunks (5 pages of 7000 rows against 3 of 11000) in one page-list evaluation
+      std::vector<uint64_t> words;
+      int64_t rows = 0;
+      CHECK(scanner.EvalSimplePredicatesChunks(&words, &rows));
+      CHECK(rows == n);
+      int64_t wrong = 0;
+      for (int i = 0; i < n; ++i) wrong += (((words[(size_t)i >> 6] >> (i & 63)) & 1) != 0) != expect(i);
+      CHECK(wrong == 0);
+    }
     int64_t row = 0, bad = 0, selected = 0;
     while (row < n) {
       SkipBitset bs;

@@ -283,7 +283,9 @@ ips_status ips_dict_select(const ips_dict* dict, const void* d_codes_enc, int64_
  *   d_dense_values    the values of the selected NON-NULL rows, dense, in row order (dictionary
  *                     entries of ips slot width when dict != NULL, else the raw 4-byte FLE values)
  *   d_nonnull_flags   one bit per SELECTED row, 1 = not NULL (ceil(n_rows/64) words reserved)
- *   d_counts          int64[2]: [0] selected rows, [1] selected non-NULL rows
+ *   d_counts          int64[3]: [0] selected rows, [1] selected non-NULL rows, [2] non-zero when a
+ *                     selected code lies outside the dictionary (DictDecoder::GetValue returns false,
+ *                     dict-encoding.h:316; the slot of such a row is left unwritten)
  * d_def_levels / n_data_rows as in ips_fle_pred_nullable; d_selection: ceil(n_rows/64) words.
  * Workspace: ips_select_nullable_workspace_bytes(n_rows, n_data_rows, value_width 4 | 8). */
 size_t ips_select_nullable_workspace_bytes(int64_t n_rows, int64_t n_data_rows, int value_width);
@@ -331,6 +333,11 @@ ips_status ips_bitmap_fill(uint64_t* d_a, int64_t n_rows, int value, ips_stream 
 /* dynamic_bitset::count(), hdfs-parquet-scanner.cc:344,1125; d_count is int64 */
 ips_status ips_bitmap_count(const uint64_t* d_a, int64_t n_rows, int64_t* d_count,
                             ips_stream stream);
+/* The selected rows of every IPS_BATCH_ROWS-row batch of a selection (uint32 per batch): what the
+ * fused scans write next to their values, for selections that come from elsewhere (the skip-list
+ * walk of hdfs-parquet-scanner.cc:1134-1148 counts them row by row). */
+ips_status ips_bitmap_batch_counts(const uint64_t* d_a, int64_t n_rows, uint32_t* d_batch_counts,
+                                   ips_stream stream);
 /* ColumnReader::IntersectBitset, hdfs-parquet-scanner.cc:326-331: the j-th set bit of d_root
  * takes bit j of d_sub; cleared bits stay 0.  Workspace: ips_expand_workspace_bytes(n_rows). */
 size_t ips_expand_workspace_bytes(int64_t n_rows);
@@ -484,7 +491,9 @@ ips_status ips_allgather_bitmap(ips_comm* comm, const uint64_t* d_local_words, i
  * (w = piece words) in natural row order.  Chunk i is scanned by ips_fle_scan on 'stream' and
  * gathered on the communicator's own stream as soon as it is done, while chunk i + 1 is scanned.
  * Outputs d_local_bitmap / d_batch_values / d_batch_counts as ips_fle_scan over the n_rows local
- * rows.  ips_comm_join makes a stream wait for all gathers issued so far. */
+ * rows.  The call first makes 'stream' wait for the gathers of earlier calls (they may still read
+ * d_local_bitmap), so the buffers can be reused step after step; ips_comm_join makes any stream
+ * wait for all gathers issued so far (before d_all_bitmap is read). */
 ips_status ips_fle_scan_allgather(ips_comm* comm, const void* d_enc, int64_t n_rows, int bit_width,
                                   ips_op op, const uint64_t* consts, int n_consts, int n_chunks,
                                   uint64_t* d_local_bitmap, uint32_t* d_batch_values,

@@ -282,3 +282,67 @@ def test_chunk_aligned_pages_equal_contiguous(capi, ips, O):
     assert torch.equal(got, ref)
     for ch in chunks:
         ch.close()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_chunk_tiny_pages_share_words(capi, O, seed):
+    """Hundreds of pages of 1..70 rows: several pages inside one bitmap dword, every kernel family
+    (FLE predicate incl. w = 32 early pruning, nullable leaf, PLAIN 4- and 8-byte) in store / AND / OR
+    mode against the oracle page by page."""
+    rng = np.random.default_rng(900 + seed)
+    n = 9000 + int(rng.integers(0, 64))
+    tiny = list(range(0, 71))
+    v0 = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    v0[::5] = (v0[7] & 0xFFFF0000) | (v0[::5] & 0xFFFF)        # rows undecided after the high planes
+    ch0, h0 = fle_chunk(capi, O, v0, cuts(rng, n, tiny), lambda i: 32)
+    v1 = rng.integers(0, 1 << 9, n).astype(np.uint32)
+    ch1, h1 = fle_chunk(capi, O, v1, cuts(rng, n, tiny), lambda i: 9)
+    is_set = rng.random(n) >= 0.3
+    v2 = rng.integers(0, 1 << 4, n).astype(np.uint32)
+    pages2, host2, pos = [], [], 0
+    for m in cuts(rng, n, [m for m in tiny if m]):
+        s_ = is_set[pos:pos + m]
+        k = int(s_.sum())
+        defs = O.fle_encode(s_.astype(np.uint32), 1)
+        enc = O.fle_encode(v2[pos:pos + m][s_], 4) if k else np.zeros(2, np.uint64)
+        pages2.append((dev_words(enc), m, 4, dev_words(defs), ((k + 63) // 64) * 64))
+        host2.append((defs, m, enc, k))
+        pos += m
+    ch2 = capi.Chunk(pages2, max_def_level=1)
+    p64 = rng.integers(-10 ** 6, 10 ** 6, n).astype(np.int64)
+    pages3, host3, pos = [], [], 0
+    for m in cuts(rng, n, [m for m in tiny if m]):
+        pages3.append((torch.from_numpy(np.ascontiguousarray(p64[pos:pos + m])).cuda(), m, 0))
+        host3.append((O.plain_encode(p64[pos:pos + m], capi.T_INT64), m))
+        pos += m
+    ch3 = capi.Chunk(pages3, encoding=capi.COL_PLAIN, type_=capi.T_INT64)
+    c0 = int(v0[7])
+    a = (capi.leaf(0, O.OP_LT, c0), oracle_fle_pred_pages(O, h0, O.OP_LT, c0))
+    b = (capi.leaf(0, O.OP_GE, c0 & 0xFFFF0000), oracle_fle_pred_pages(O, h0, O.OP_GE, c0 & 0xFFFF0000))
+    c = (capi.leaf(1, O.OP_IN, [1, 100, 511]), oracle_fle_pred_pages(O, h1, O.OP_IN, [1, 100, 511]))
+    d = (capi.leaf(2, O.OP_GE, 7), np.concatenate([oracle_nullable_page(O, df, m, e, k, 4, O.OP_GE, 7) for df, m, e, k in host2]))
+    e = (capi.plain_leaf(3, O.OP_LT, np.int64(1000), capi.T_INT64),
+         np.concatenate([bits_of(O.plain_pred(pg, m, capi.T_INT64, O.OP_LT, np.int64(1000), O.SEM_SQL), m) for pg, m in host3]))
+    AND, OR = capi.and_node, capi.or_node
+    chunks = [ch0, ch1, ch2, ch3]
+    for nodes, exp in (([a[0]], a[1]), ([d[0]], d[1]), ([e[0]], e[1]),
+                       ([a[0], b[0], AND()], a[1] & b[1]),
+                       ([c[0], d[0], AND(), e[0], AND(), a[0], OR()], (c[1] & d[1] & e[1]) | a[1]),
+                       ([e[0], d[0], OR(), c[0], OR(), b[0], AND()], (e[1] | d[1] | c[1]) & b[1])):
+        got = capi.eval_program_chunks(nodes, chunks)
+        assert np.array_equal(words(got), pack(exp)), (seed, len(nodes))
+    bitmap, bvals, counts = ch1.fle_scan(O.OP_IN, [1, 100, 511])
+    assert np.array_equal(words(bitmap), pack(c[1]))
+    assert np.array_equal(ch1.compact(bvals, counts).cpu().numpy().view(np.uint32), v1[c[1]])
+    for ch in chunks:
+        ch.close()
+
+
+def test_bitmap_batch_counts(capi):
+    rng = np.random.default_rng(5)
+    for n in (1, 2047, 2048, 2049, 100003):
+        bits = rng.random(n) < 0.3
+        bm = torch.from_numpy(pack(bits).view(np.int64).copy()).cuda()
+        got = capi.bitmap_batch_counts(bm, n).cpu().numpy()
+        exp = np.add.reduceat(bits.astype(np.int64), np.arange(0, n, 2048))
+        assert np.array_equal(got, exp), n

@@ -380,3 +380,58 @@ def test_config2_2p28_rows_int64_and_gt_lt(capi, ips):
             del bv
         del g, l, mask, packed
     dd.close()
+
+
+def test_page_lists_at_full_size(capi, ips):
+    """configs[4] and configs[3] over SEPARATE page buffers (ips_chunk_*): the Q6 conjunction over
+    600,037,902 rows with the three columns cut into pages of different sizes (2^20, 2^20 - 37 and
+    700,001 rows: every page boundary of every column falls inside a bitmap word), and the
+    dictionary IN scan + gather over 257 unaligned pages -- the very words / values of the
+    contiguous-buffer calls (themselves checked against torch above)."""
+    q6 = ips.q6
+    n = q6.ROWS
+    codes = [q6.codes_gpu(capi, c, n) for c in range(3)]
+    encs = [capi.fle_encode(codes[c], q6.COLUMNS[c][3]) for c in range(3)]
+    nodes, cols = q6.program(capi, encs)
+    ref = capi.eval_program(nodes, cols, n)
+    assert torch.equal(ref, _pack_rows(q6.truth(codes)))
+    del encs, cols
+
+    def chunk_of(vals, w, rows):
+        pages, pos = [], 0
+        while pos < vals.numel():
+            m = min(rows, vals.numel() - pos)
+            pages.append((capi.fle_encode(vals[pos:pos + m].clone(), w), m, w))
+            pos += m
+        return capi.Chunk(pages)
+    chunks = [chunk_of(codes[c], q6.COLUMNS[c][3], r) for c, r in enumerate((1 << 20, (1 << 20) - 37, 700001))]
+    got = capi.eval_program_chunks(nodes, chunks)
+    assert torch.equal(got, ref)
+    for ch in chunks:
+        ch.close()
+    del chunks, codes, got, ref
+    torch.cuda.empty_cache()
+    n = 1 << 28
+    rng = np.random.default_rng(4)
+    D, bw = 4096, 12
+    dict_vals = np.sort(rng.choice(np.arange(-2 ** 30, 2 ** 30, 7), D, replace=False)).astype(np.int32)
+    cds = ((capi.synth_u32(ips.synth.SEED_DICT, n, 32).to(torch.int64) & 0xFFFFFFFF) % D).to(torch.int32)
+    dd = capi.Dict(dict_vals.view(np.uint8), capi.T_INT32)
+    present = rng.choice(D, 8, replace=False)
+    lits = np.concatenate([dict_vals[present], dict_vals[present] + 1]).astype(np.int32)
+    chunk = chunk_of(cds, bw, (1 << 20) - 37)
+    bitmap, bvals, counts = chunk.dict_scan(dd, capi.OP_IN, lits)
+    mask = torch.isin(cds, torch.tensor(np.sort(present), device="cuda", dtype=torch.int32))
+    assert torch.equal(bitmap, _pack_rows(mask))
+    d_dict = torch.from_numpy(dict_vals).cuda()
+    assert torch.equal(chunk.compact(bvals, counts), d_dict[torch.masked_select(cds, mask).to(torch.int64)])
+    chunk.close()
+    dd.close()
+
+
+def _pack_rows(mask):
+    n = mask.numel()
+    pad = (-n) % 64
+    if pad:
+        mask = torch.cat([mask, torch.zeros(pad, dtype=torch.bool, device=mask.device)])
+    return _pack(mask)

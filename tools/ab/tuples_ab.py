@@ -27,7 +27,7 @@ bm, bvals, counts = outs
 nsel = int(counts.to(torch.int64).sum().item())
 bv64 = torch.arange(n, dtype=torch.int64, device=dev)
 ws = torch.empty(int(lib.ips_assemble_workspace_bytes(N, 2)) + 256, dtype=torch.uint8, device=dev)
-cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+cnt = torch.zeros(3, dtype=torch.int64, device=dev)
 for name, layout, ts in (("int32,int64,int32 -> 24 B", ((4, 0), (8, 8), (4, 16)), 24),
                          ("4 x int32 -> 32 B", ((4, 0), (4, 8), (4, 16), (4, 24)), 32),
                          ("8 x int32 -> 64 B", tuple((4, 8 * i) for i in range(8)), 64)):

@@ -32,7 +32,7 @@ bm2 = capi.fle_pred(enc, n, 32, capi.OP_GE, 1 << 31).clone()          # 50 % mas
 ws = torch.empty(max(int(lib.ips_expand_workspace_bytes(N)), int(lib.ips_batches_workspace_bytes(N)),
                      int(lib.ips_assemble_workspace_bytes(N, 2)), 16), dtype=torch.uint8, device=dev)
 out_bm = torch.empty(W + 2, dtype=torch.int64, device=dev)
-cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+cnt = torch.zeros(3, dtype=torch.int64, device=dev)
 dense = torch.empty(n, dtype=torch.int32, device=dev)
 acc = bm.clone()
 

@@ -100,7 +100,7 @@ S = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 ws = torch.empty(max(int(lib.ips_expand_workspace_bytes(N)), int(lib.ips_batches_workspace_bytes(N)),
                      int(lib.ips_assemble_workspace_bytes(N, 2)), 16) + 256, dtype=torch.uint8, device=dev)
 out_bm = torch.empty(W + 2, dtype=torch.int64, device=dev)
-cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+cnt = torch.zeros(3, dtype=torch.int64, device=dev)
 dense = torch.empty(n, dtype=torch.int32, device=dev)
 run("bitmap_and", "bitmap_binop_kernel", 3 * W * 8, lambda: lib.ips_bitmap_and(P(acc), P(bm50), N, S))
 run("bitmap_count", "bitmap_count_kernel", W * 8, lambda: lib.ips_bitmap_count(P(bm10), N, P(cnt), S))
@@ -166,7 +166,7 @@ sel_bm = bm.clone()
 n_sel_nn = capi.bitmap_count(sel_bm, n)
 dense_sn = torch.empty(n_sel_nn + 64, dtype=torch.int32, device=dev)
 flags_sn = torch.empty(W, dtype=torch.int64, device=dev)
-cnt_sn = torch.zeros(2, dtype=torch.int64, device=dev)
+cnt_sn = torch.zeros(3, dtype=torch.int64, device=dev)
 run("select_nullable w=12, 10% NULL, the leaf's selection (counts + select)", "fle_select_nullable_kernel<12, 0>",
     W * 16 + n_data // 64 * 96 + 4 * n_sel_nn + n_sel_nn // 8,
     lambda: capi._ck(lib.ips_dict_select_nullable(None, P(defs), 1, 1, N, P(venc), C.c_int64(n_data), 12, P(sel_bm), P(dense_sn),
