@@ -455,18 +455,16 @@ def main():
         # the data-path exchange goes through the C-ABI (what a C++ host calls): RCCL communicator
         # created from an id that rank 0 makes and the bootstrap distributes
         idt = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        # RCCL prints a version banner on stdout (through the C library's buffer, whenever it likes):
+        # fd 1 points at stderr until the ONE JSON line is due
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         if rank == 0:
             idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, 0)
-        sys.stdout.flush()
-        saved = os.dup(1)  # RCCL prints a version banner on stdout: keep stdout to the ONE JSON line
-        os.dup2(2, 1)
-        try:
-            comm = capi.Comm(bytes(idt.cpu().numpy().tobytes()), world, rank)
-            torch.cuda.synchronize()
-        finally:
-            os.dup2(saved, 1)
-            os.close(saved)
+        comm = capi.Comm(bytes(idt.cpu().numpy().tobytes()), world, rank)
+        torch.cuda.synchronize()
 
     n, bw = args.rows, args.bw
     c = ips.synth.lt_constant(bw, args.sel)
@@ -584,6 +582,7 @@ def main():
         kern_ms = sorted(a.elapsed_time(b) for a, b in single)
 
     if gather:  # bit-identity of the exchange
+        comm.check()  # no waiter of a step gave up
         for i in range(n_chunks):  # piece (i, rank) of the gathered bitmap is this rank's chunk i
             g0 = (i * world + rank) * words_c
             assert torch.equal(full_bm[g0:g0 + words_c], local_bm[i * words_c:(i + 1) * words_c]), \
@@ -751,8 +750,13 @@ def main():
             "note": "value includes the all-gathers (chunk i's exchange overlaps the scan of chunk i+1 and of the "
                     "next step); scan_only = total rows / rank 0's average per-step scan time in the same run"}
         out["extra"]["q6_sharded"] = q6_sharded
-    print(json.dumps(out))
     if gather:
+        C.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+    print(json.dumps(out), flush=True)
+    if gather:
+        os.dup2(2, 1)
         comm.close()
         dist.destroy_process_group()
 
@@ -766,29 +770,29 @@ def leg_q6_sharded(ips, capi, dev, dist, comm, comm_stream, world, rank):
     piece_rows, pieces = sh.cyclic_pieces(n, world, rank, N_CHUNKS)
     pw = piece_rows // 64
     stream = torch.cuda.current_stream()
+    # every rank holds N_CHUNKS pieces of piece_rows rows per column (pieces beyond the data are padded
+    # with rows that select nothing: code 0 fails "shipdate >= 365"), each column as ONE ips_chunk whose
+    # pages are the pieces; one C call per step: ips_eval_program_chunks_allgather
     data = []
+    col_pages = [[], [], []]
     for row0, row1 in pieces:
-        m = row1 - row0
-        if m <= 0:
-            data.append(None)
-            continue
-        codes, encs = q6_piece(ips, capi, dev, row0, m)
-        nodes, cols = q6.program(capi, encs)
-        data.append((m, codes, encs, nodes, cols))
+        m = max(row1 - row0, 0)
+        codes = [q6.codes_gpu(capi, c, m, start=row0, device=dev) if m else torch.zeros(0, dtype=torch.int32, device=dev)
+                 for c in range(3)]
+        data.append((m, codes))
+        for c in range(3):
+            padded = torch.zeros(piece_rows, dtype=torch.int32, device=dev)
+            padded[:m] = codes[c]
+            w = q6.COLUMNS[c][3]
+            col_pages[c].append((capi.fle_encode(padded, w), piece_rows, w))
+    chunks = [capi.Chunk(col_pages[c]) for c in range(3)]
+    nodes, _ = q6.program(capi, [pg[0][0] for pg in col_pages])
     local = torch.zeros(N_CHUNKS * pw, dtype=torch.int64, device=dev)
     full = torch.empty(N_CHUNKS * world * pw, dtype=torch.int64, device=dev)
 
     def run():
-        for i, d in enumerate(data):
-            if d is not None:
-                m, _, _, nodes, cols = d
-                capi.eval_program(nodes, cols, m, bitmap=local[i * pw:(i + 1) * pw])
-            done = stream.record_event()
-            comm_stream.wait_event(done)
-            capi._ck(capi.lib().ips_allgather_bitmap(
-                comm.h, C.c_void_p(local[i * pw:].data_ptr()), C.c_int64(pw),
-                C.c_void_p(full[i * world * pw:].data_ptr()), C.c_void_p(comm_stream.cuda_stream)))
-        stream.wait_event(comm_stream.record_event())
+        comm.eval_program_chunks_allgather(nodes, chunks, local, full, stream=stream)
+        comm.join(stream)
 
     for _ in range(2):
         run()
@@ -805,13 +809,13 @@ def leg_q6_sharded(ips, capi, dev, dist, comm, comm_stream, world, rank):
     t = float(el.item()) / reps
     # checks: this rank's pieces against torch on the raw codes; all ranks hold the same words
     ok = True
-    for i, d in enumerate(data):
-        if d is None:
+    for i, (m, codes) in enumerate(data):
+        if m == 0:
             continue
-        m, codes = d[0], d[1]
         g0 = (i * world + rank) * pw
         exp = pack_mask(q6.truth(codes))
         ok = ok and torch.equal(full[g0:g0 + exp.numel()], exp)
+    comm.check()
     chk = full[:(n + 63) // 64].sum().reshape(1).clone()
     lo, hi = chk.clone(), chk.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -823,6 +827,8 @@ def leg_q6_sharded(ips, capi, dev, dist, comm, comm_stream, world, rank):
             "rows_per_s": round(n / t, 1), "algorithmic_bytes": q6.algorithmic_bytes(n),
             "GBps_aggregate": round(q6.algorithmic_bytes(n) / t / 1e9, 1), "scaling": "strong",
             "check": bool(okt.item()),
+            "launches_per_step": "3 predicate launches over all pieces (ips_eval_program_chunks_allgather) + one "
+                                 "waiter and one ncclAllGather per piece on the communicator's stream",
             "check_detail": "each rank's gathered pieces vs torch on the raw codes; all ranks hold identical words"}
 
 

@@ -51,7 +51,7 @@ SYMBOLS = [
     "ips_chunk_program_workspace_bytes", "ips_eval_program_chunks", "ips_chunk_fle_scan", "ips_chunk_dict_scan",
     "ips_chunk_plain_scan", "ips_chunk_select",
     "ips_comm_unique_id", "ips_comm_init", "ips_comm_destroy", "ips_allgather_bitmap",
-    "ips_fle_scan_allgather", "ips_comm_join",
+    "ips_fle_scan_allgather", "ips_comm_join", "ips_eval_program_chunks_allgather", "ips_comm_check",
 ]
 
 
@@ -733,6 +733,16 @@ class Comm:
 
     def join(self, stream=None):
         _ck(lib().ips_comm_join(self.h, _stream(stream)))
+
+    def eval_program_chunks_allgather(self, nodes, chunks, local_bitmap, full_bitmap, workspace=None, stream=None):
+        """ips_eval_program_chunks_allgather: one call per step of the sharded predicate tree."""
+        arr_n = (Node * len(nodes))(*nodes)
+        arr_c = (C.c_void_p * len(chunks))(*[c.h for c in chunks])
+        _ck(lib().ips_eval_program_chunks_allgather(self.h, arr_n, len(nodes), arr_c, len(chunks), _ptr(local_bitmap),
+                                                    _ptr(full_bitmap), _ptr(workspace), _stream(stream)))
+
+    def check(self):
+        _ck(lib().ips_comm_check(self.h))
 
     def close(self):
         if self.h:

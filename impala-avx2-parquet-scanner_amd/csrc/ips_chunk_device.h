@@ -47,10 +47,22 @@ struct BitmapWindow {
   int64_t tail_dword;    // last page: page-relative index of the dword that holds the chunk's last row
   uint32_t tail_mask;    //            its bits behind that row
   uint32_t tail_extra;   //            1: the bitmap's last word has one more dword behind it
+  uint32_t coherent;     // 1: the dwords are stored device-coherently (written through to memory: a sharded
+                         //    step hands pages to the exchange while the launch is still running, page_done)
 };
 
-__device__ __forceinline__ BitmapWindow bitmap_window(uint32_t* bitmap32, const ChunkPage& pg, int64_t chunk_rows) {
+__device__ __forceinline__ void window_store(uint32_t* p, uint32_t v, uint32_t coherent) {
+  if (coherent) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else IPS_BITMAP_STORE(p, v);
+}
+
+__device__ __forceinline__ BitmapWindow bitmap_window(uint32_t* bitmap32, const ChunkPage& pg, int64_t chunk_rows,
+                                                      const void* done = nullptr) {
   BitmapWindow w;
+  // (device-coherent dword stores were tried for pages that are handed on while the launch is still
+  // running: 439 us instead of 224 for the w = 32 scan -- the bitmap stays nt stores, see page_done)
+  w.coherent = 0u;
+  (void)done;
   w.base = bitmap32 + (pg.row0 >> 5);
   w.shift = (uint32_t)(pg.row0 & 31);
   w.own_tail = pg.flags & kPageLast;
@@ -65,12 +77,12 @@ __device__ __forceinline__ BitmapWindow bitmap_window(uint32_t* bitmap32, const 
 
 // one dword of the chunk-wide bitmap: 'mask' = the bits this lane owns, 'val' its values there
 // (val & ~mask == 0).  combine: 0 store, 1 AND into, 2 OR into.
-__device__ __forceinline__ void window_put(uint32_t* p, uint32_t val, uint32_t mask, int combine) {
+__device__ __forceinline__ void window_put(uint32_t* p, uint32_t val, uint32_t mask, int combine, uint32_t coherent) {
   if (mask == 0u) return;
   if (mask == ~0u) {
     if (combine == 1) val &= *p;
     else if (combine == 2) val |= *p;
-    IPS_BITMAP_STORE(p, val);
+    window_store(p, val, coherent);
     return;
   }
 #ifdef IPS_WINDOW_ABLATE  // dev (timing only, results are wrong): no merging of shared dwords
@@ -104,8 +116,8 @@ __device__ __forceinline__ void window_flush(const BitmapWindow& w, WindowCarry&
     uint32_t m2 = cy.vm >> r;
     const bool tail = w.own_tail && cy.next == w.tail_dword && m2 != 0u;
     if (tail) m2 |= w.tail_mask;
-    window_put(w.base + cy.next, cy.bm >> r, m2, combine);
-    if (tail && w.tail_extra && combine != 2) IPS_BITMAP_STORE(w.base + cy.next + 1, 0u);
+    window_put(w.base + cy.next, cy.bm >> r, m2, combine, w.coherent);
+    if (tail && w.tail_extra && combine != 2) window_store(w.base + cy.next + 1, 0u, w.coherent);
   }
   cy.next = -1;
   cy.bm = cy.vm = 0u;
@@ -137,8 +149,8 @@ __device__ __forceinline__ void window_emit(const BitmapWindow& w, WindowCarry& 
   }
   const bool tail = w.own_tail && d == w.tail_dword && mask != 0u;  // zeros behind the chunk's last row
   if (tail) mask |= w.tail_mask;
-  window_put(w.base + d, val, mask, combine);
-  if (tail && w.tail_extra && combine != 2) IPS_BITMAP_STORE(w.base + d + 1, 0u);
+  window_put(w.base + d, val, mask, combine, w.coherent);
+  if (tail && w.tail_extra && combine != 2) window_store(w.base + d + 1, 0u, w.coherent);
 }
 
 // The same for a wave whose lanes hold FOUR consecutive dwords each (two 64-bit words per lane, the
@@ -173,8 +185,8 @@ __device__ __forceinline__ void window_emit_quad(const BitmapWindow& w, WindowCa
     uint32_t mask = (vm[k] << s) | pv;
     const bool tail = w.own_tail && d0 + k == w.tail_dword && mask != 0u;
     if (tail) mask |= w.tail_mask;
-    window_put(w.base + d0 + k, val, mask, combine);
-    if (tail && w.tail_extra && combine != 2) IPS_BITMAP_STORE(w.base + d0 + k + 1, 0u);
+    window_put(w.base + d0 + k, val, mask, combine, w.coherent);
+    if (tail && w.tail_extra && combine != 2) window_store(w.base + d0 + k + 1, 0u, w.coherent);
     pb = s != 0u ? bm[k] >> r : 0u;
     pv = s != 0u ? vm[k] >> r : 0u;
   }
@@ -215,6 +227,60 @@ __device__ __forceinline__ uint32_t window_fetch(const uint32_t* __restrict__ bi
     x = (lo >> s) | (hi << (32u - s));
   }
   return valid >= 32 ? x : valid <= 0 ? 0u : (x & ((1u << valid) - 1u));
+}
+
+// End of a wave's work on page blockIdx.y of a launch whose pages are being waited for one by one
+// (the exchange of a sharded step starts on a page's bitmap words while later pages are still being
+// scanned): the wave's stores become visible device-wide, then it counts itself; the wave that makes
+// the count gridDim.x * waves-per-workgroup raises the page's flag, which is what the waiter polls.
+// Layout of the completion words (uint32, device memory owned by the waiter's side):
+//   sub[page][k]   k < kDoneSubs, each in its own 128-byte line: waves (index % kDoneSubs == k) finished
+//   top[page]      sub-counters that are complete
+//   flag[page]     the page is complete (what the waiter polls)
+// Every wave of a 2^28-row launch adding to ONE word per page serialises 8192 device-scope atomics on
+// one address: ~50 ns each, 0.42 ms for a 0.21 ms scan (profiles/round3_sharded_step.md).  Spread over
+// kDoneSubs lines the chains are 64 atomics long and run side by side.
+constexpr int kDonePages = 64;
+constexpr int kDoneSubs = 64;
+constexpr int kDoneLine = 32;  // uint32 per 128-byte line
+constexpr int kDoneTop = kDonePages * kDoneSubs * kDoneLine;
+constexpr int kDoneFlag = kDoneTop + kDonePages * kDoneLine;
+constexpr int kDoneWords = kDoneFlag + kDonePages * kDoneLine;  // (+ 1: the waiters' timeout word)
+
+// The counters clean up after themselves: the wave that completes a page -- every wave of the page
+// has counted by then, and the next step's launch starts after this one -- zeroes them before it
+// raises the flag, and the flag takes the step's EPOCH (a new value every step), so nothing has to
+// be reset between steps (a 528-KB memset + an event per step: 24 us of a 0.21-ms scan).
+__device__ __forceinline__ void page_done(uint32_t* done, int page0, uint32_t epoch) {
+  if (done == nullptr) return;
+  // The wave waits until its stores have been taken by its XCD's L2 and counts itself; nothing is
+  // flushed here.  A device-scope release per wave writes back (and with __threadfence also
+  // invalidates) the whole L2 under the feet of every wave still streaming: 1.66 ms / 3.2 ms for a
+  // 0.21 ms scan; device-coherent bitmap stores: 0.44 ms.  The dirty bitmap lines reach memory when
+  // the waiter kernel on the consumer's stream ENDS: a kernel's end is a release over all L2s, the
+  // same flush a piece-by-piece launch sequence gets from its kernel boundaries.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    const uint32_t waves_per_block = blockDim.x / kWave;
+    const uint32_t all = gridDim.x * waves_per_block;
+    const uint32_t idx = blockIdx.x * waves_per_block + (threadIdx.x / kWave);
+    const uint32_t subs = all < (uint32_t)kDoneSubs ? all : (uint32_t)kDoneSubs;
+    const uint32_t k = idx % subs;
+    const uint32_t mine = (all - k + subs - 1u) / subs;  // waves that count on sub-counter k
+    const int page = page0 + (int)blockIdx.y;
+    uint32_t* sub = done + ((size_t)page * kDoneSubs + k) * kDoneLine;
+    if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == mine) {
+      uint32_t* top = done + kDoneTop + (size_t)page * kDoneLine;
+      if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == subs) {
+        for (uint32_t j = 0; j < subs; ++j)
+          __hip_atomic_store(done + ((size_t)page * kDoneSubs + j) * kDoneLine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+        __hip_atomic_store(done + kDoneFlag + (size_t)page * kDoneLine, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 
 // the page a workgroup works on (blockIdx.y of a paged launch)

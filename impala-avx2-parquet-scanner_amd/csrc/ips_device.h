@@ -47,6 +47,11 @@ struct PredArgs {
   const void* aux_root;
   int64_t aux_rows;
   uint32_t* aux_counts;
+  // paged launches of a sharded step (ips_comm.hip): every wave adds one to done[blockIdx.y] when the
+  // results of its share of page blockIdx.y are visible device-wide; NULL = nobody is waiting
+  uint32_t* done;
+  int32_t done_page0;  // page index of blockIdx.y == 0 in 'done' (the first page of the launch's run)
+  uint32_t done_epoch; // the value a complete page's flag takes in this step
   uint32_t consts[256];
 };
 

@@ -577,7 +577,7 @@ __global__ __launch_bounds__(kThreads, (ScanLds<W, MODE>::kMinWaves)) void fle_s
     uint32_t dict_entries, int32_t* __restrict__ bad_index) {
   PageCtx pc;
   pc.page = pages[blockIdx.y];
-  pc.win = bitmap_window(bitmap32, pc.page, chunk_rows);
+  pc.win = bitmap_window(bitmap32, pc.page, chunk_rows, args.done);
   pc.total_dwords = bitmap_dwords(chunk_rows);
   const TileShare sh = tile_share(pc.win, (pc.page.n_data + kRowsPerTile - 1) / kRowsPerTile,
                                   (int64_t)blockIdx.x * kWavesPerBlock + wave_id(), (int64_t)gridDim.x * kWavesPerBlock);
@@ -585,6 +585,7 @@ __global__ __launch_bounds__(kThreads, (ScanLds<W, MODE>::kMinWaves)) void fle_s
                                   batch_values + (int64_t)pc.page.batch0 * kRowsPerTile,
                                   batch_counts + pc.page.batch0, dict, dict_entries, bad_index, sh.first, sh.step,
                                   &pc, sh.end);
+  page_done(args.done, args.done_page0, args.done_epoch);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -682,8 +683,9 @@ template <int W, int KIND>
 __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_pages_kernel(
     const ChunkPage* __restrict__ pages, int64_t chunk_rows, PredArgs args, uint32_t* __restrict__ bitmap32) {
   const ChunkPage pg = pages[blockIdx.y];
-  const BitmapWindow win = bitmap_window(bitmap32, pg, chunk_rows);
+  const BitmapWindow win = bitmap_window(bitmap32, pg, chunk_rows, args.done);
   fle_pred_body<W, KIND, true>(pg.data, pg.n_data, args, nullptr, &win);
+  page_done(args.done, args.done_page0, args.done_epoch);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -933,7 +935,7 @@ __device__ __forceinline__ void fle_leaf_body(const uint64_t* __restrict__ enc, 
     if constexpr (PAGED) {
       // whole words on a 16-byte boundary of the chunk's bitmap take the stores below; everything
       // else goes dword by dword through the window (shifted, shared dwords merged atomically)
-      if (!(whole && win->shift == 0u && (reinterpret_cast<uintptr_t>(win->base) & 15u) == 0u)) {
+      if (!(whole && win->shift == 0u && win->coherent == 0u && (reinterpret_cast<uintptr_t>(win->base) & 15u) == 0u)) {
         const uint32_t in[4] = {(uint32_t)res[0], (uint32_t)(res[0] >> 32), (uint32_t)res[1], (uint32_t)(res[1] >> 32)};
         window_emit_quad(*win, carry, 2 * w0, in, args.combine);
         continue;
@@ -968,11 +970,15 @@ template <int W, int KIND>
 __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_leaf_pages_kernel(
     const ChunkPage* __restrict__ pages, int64_t chunk_rows, PredArgs args, uint32_t* __restrict__ bitmap32) {
   const ChunkPage pg = pages[blockIdx.y];
-  if ((int64_t)blockIdx.x * kExpWordsPerBlock * 64 >= pg.n_rows) return;  // (the grid is sized for the largest page)
-  const BitmapWindow win = bitmap_window(bitmap32, pg, chunk_rows);
+  if ((int64_t)blockIdx.x * kExpWordsPerBlock * 64 >= pg.n_rows) {  // (the grid is sized for the largest page)
+    page_done(args.done, args.done_page0, args.done_epoch);
+    return;
+  }
+  const BitmapWindow win = bitmap_window(bitmap32, pg, chunk_rows, args.done);
   fle_leaf_body<W, KIND, true>(pg.data, pg.n_data, args, reinterpret_cast<u64*>(win.base), &win,
                                reinterpret_cast<const u64*>(pg.levels), kRootLevels1, pg.n_rows,
                                args.aux_counts + pg.rank0);
+  page_done(args.done, args.done_page0, args.done_epoch);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1408,8 +1414,9 @@ template <int W, bool PAIR>
 __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_early_pages_kernel(
     const ChunkPage* __restrict__ pages, int64_t chunk_rows, PredArgs args, uint32_t* __restrict__ bitmap32) {
   const ChunkPage pg = pages[blockIdx.y];
-  const BitmapWindow win = bitmap_window(bitmap32, pg, chunk_rows);
+  const BitmapWindow win = bitmap_window(bitmap32, pg, chunk_rows, args.done);
   fle_pred32_early_body<W, PAIR, true>(pg.data, pg.n_data, args, nullptr, &win);
+  page_done(args.done, args.done_page0, args.done_epoch);
 }
 
 // ---------------------------------------------------------------------------------------------

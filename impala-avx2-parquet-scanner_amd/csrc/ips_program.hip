@@ -972,8 +972,11 @@ struct ChunkCtx {
   bool counted[IPS_PROGRAM_MAX_COLS] = {};
 };
 
+// done: the launches count their waves per page (the last operand of a sharded step), or NULL;
+// *signalled = false when this operand has no counting kernel
 ips_status emit_item_chunk(const ChainItem& it, int combine, const ips_chunk* const* chunks, int64_t n_rows,
-                           uint64_t* d_bitmap, ChunkCtx& ctx, hipStream_t s) {
+                           uint64_t* d_bitmap, ChunkCtx& ctx, hipStream_t s, uint32_t* done = nullptr,
+                           bool* signalled = nullptr, uint32_t done_epoch = 0) {
   const int col = it.a->column;
   const ips_chunk* c = chunks[col];
   if (c->pages.empty()) return IPS_OK;
@@ -991,6 +994,12 @@ ips_status emit_item_chunk(const ChainItem& it, int combine, const ips_chunk* co
       run_pred_args(run.bit_width, it.a->op, it.a->consts, it.a->n_consts, it.b ? it.join : 0, it.b ? it.b->op : 0,
                     it.b ? it.b->consts[0] : 0, combine, &args);
       ips_status st;
+      if (done) {
+        args.done = done;
+        args.done_page0 = run.first;
+        args.done_epoch = done_epoch;
+        *signalled = true;
+      }
       if (c->max_def_level > 0) {
         args.aux_counts = ctx.rank[col];
         st = launch_fle_leaf_pages(run.bit_width, c->d_pages + run.first, run.count, run.max_rows, n_rows, args, bm32, s);
@@ -1052,9 +1061,11 @@ extern "C" size_t ips_chunk_program_workspace_bytes(const ips_node* nodes, int n
   return bytes;
 }
 
-extern "C" ips_status ips_eval_program_chunks(const ips_node* nodes, int n_nodes, const ips_chunk* const* chunks,
-                                              int n_chunks, uint64_t* d_bitmap, void* d_workspace,
-                                              ips_stream stream) {
+namespace ips {
+ips_status eval_program_chunks_signalled(const ips_node* nodes, int n_nodes, const ips_chunk* const* chunks, int n_chunks,
+                                         uint64_t* d_bitmap, void* d_workspace, uint32_t* done, uint32_t done_epoch,
+                                         bool* signalled, hipStream_t s) {
+  if (signalled) *signalled = false;
   int64_t n_rows = 0;
   ips_status st = check_chunk_program(nodes, n_nodes, chunks, n_chunks, &n_rows);
   if (st != IPS_OK) return st;
@@ -1068,7 +1079,6 @@ extern "C" ips_status ips_eval_program_chunks(const ips_node* nodes, int n_nodes
   const size_t need = ips_chunk_program_workspace_bytes(nodes, n_nodes, chunks, n_chunks);
   IPS_REQUIRE(need == 0 || (d_workspace && aligned16(d_workspace)),
               "ips_eval_program_chunks: pass a workspace of ips_chunk_program_workspace_bytes() bytes");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   uint8_t* temp = reinterpret_cast<uint8_t*>(d_workspace);
   const size_t slot_bytes = plan_slot_bytes(n_rows);
   ChunkCtx ctx;
@@ -1086,10 +1096,20 @@ extern "C" ips_status ips_eval_program_chunks(const ips_node* nodes, int n_nodes
   };
   for (int i = 0; i < pl.n_steps && st == IPS_OK; ++i) {
     const Step& p = pl.steps[i];
+    const bool last = i + 1 == pl.n_steps;
     if (p.kind == 0)
-      st = emit_item_chunk(ChainItem{false, p.item.a, p.item.b, p.item.join}, p.combine, chunks, n_rows, slot_ptr(p.dst), ctx, s);
+      st = emit_item_chunk(ChainItem{false, p.item.a, p.item.b, p.item.join}, p.combine, chunks, n_rows, slot_ptr(p.dst), ctx, s,
+                           last ? done : nullptr, signalled, done_epoch);
     else
       st = launch_bitmap_binop(p.combine == 1 ? 0 : 1, slot_ptr(p.dst), slot_ptr(p.src), (n_rows + 63) / 64, s);
   }
   return st;
+}
+}  // namespace ips
+
+extern "C" ips_status ips_eval_program_chunks(const ips_node* nodes, int n_nodes, const ips_chunk* const* chunks,
+                                              int n_chunks, uint64_t* d_bitmap, void* d_workspace,
+                                              ips_stream stream) {
+  return eval_program_chunks_signalled(nodes, n_nodes, chunks, n_chunks, d_bitmap, d_workspace, nullptr, 0, nullptr,
+                                       reinterpret_cast<hipStream_t>(stream));
 }

@@ -488,8 +488,9 @@ ips_status ips_allgather_bitmap(ips_comm* comm, const uint64_t* d_local_words, i
  * the rank's rows are n_chunks pieces of n_rows / n_chunks rows (a multiple of IPS_BATCH_ROWS)
  * in block-cyclic order -- piece i of rank r is piece i * nranks + r of the whole column -- so the
  * all-gather of chunk i fills words [i * nranks * w, (i + 1) * nranks * w) of d_all_bitmap
- * (w = piece words) in natural row order.  Chunk i is scanned by ips_fle_scan on 'stream' and
- * gathered on the communicator's own stream as soon as it is done, while chunk i + 1 is scanned.
+ * (w = piece words) in natural row order.  ONE launch on 'stream' scans all pieces (piece after
+ * piece in dispatch order, each signalling its completion); piece i is gathered on the
+ * communicator's own stream as soon as it is complete, while the later pieces are being scanned.
  * Outputs d_local_bitmap / d_batch_values / d_batch_counts as ips_fle_scan over the n_rows local
  * rows.  The call first makes 'stream' wait for the gathers of earlier calls (they may still read
  * d_local_bitmap), so the buffers can be reused step after step; ips_comm_join makes any stream
@@ -499,6 +500,20 @@ ips_status ips_fle_scan_allgather(ips_comm* comm, const void* d_enc, int64_t n_r
                                   uint64_t* d_local_bitmap, uint32_t* d_batch_values,
                                   uint32_t* d_batch_counts, uint64_t* d_all_bitmap, ips_stream stream);
 ips_status ips_comm_join(ips_comm* comm, ips_stream stream);
+/* The sharded step for a predicate tree over several columns (BASELINE configs[4]: the three Q6
+ * columns over the ranks): 'chunks' are the rank's column chunks, all cut alike into the exchange
+ * pieces -- the same number of pages, every page the same whole number of 64-row words on every rank
+ * -- in block-cyclic order as above.  ONE call issues the plan's launches over all pieces and the
+ * all-gather of every piece; the launches of the plan's last operand signal piece after piece, so the
+ * exchange of the early pieces overlaps the evaluation of the later ones.  d_local_bitmap: the rank's
+ * rows; workspace as ips_eval_program_chunks. */
+ips_status ips_eval_program_chunks_allgather(ips_comm* comm, const ips_node* nodes, int n_nodes,
+                                             const ips_chunk* const* chunks, int n_chunks,
+                                             uint64_t* d_local_bitmap, uint64_t* d_all_bitmap,
+                                             void* d_workspace, ips_stream stream);
+/* Synchronises with the communicator's stream; IPS_ERR_HIP if a piece of a sharded step was waited
+ * for in vain (its waiter gives up after about two seconds rather than spin for ever). */
+ips_status ips_comm_check(ips_comm* comm);
 
 /* ---- synthetic data (bench / tests) --------------------------------------------------------- */
 /* d_out[i] = splitmix64(seed + i) & mask, as uint32 (SURVEY 8d generator). */

@@ -79,11 +79,23 @@ static uint64_t consume(const ColumnChunkPages& pages, int max_def_level) {
       if (SplitDataPage(pg.bytes->data(), (int)pg.bytes->size(), max_def_level, &def, &nb, &codes, &cl)) {
         for (int i = 0; i < nb; ++i) sum += def[i];
         for (int i = 0; i < cl; ++i) sum += codes[i];
+        // the row check the scanner runs before it uploads the page: whatever it answers, it reads
+        // inside the page; when it accepts, the blocks the device will read are inside it too
+        if (CheckDictDataPage(def, nb, codes, cl, max_def_level, pg.num_values) == nullptr) {
+          const int bw = codes[0];
+          int64_t rows = pg.num_values;
+          if (max_def_level > 0) {
+            rows = CountNonNull(def, nb, max_def_level, pg.num_values);
+            for (int64_t i = 0; i < ((pg.num_values + 63) / 64) * 8; ++i) sum += def[i];
+          }
+          for (int64_t i = 0; i < ((rows + 63) / 64) * 8 * bw; ++i) sum += codes[1 + i];
+        }
       }
     } else {
       uint8_t* v = nullptr;
-      if (PlainPageValues(pg.bytes->data(), (int64_t)pg.bytes->size(), max_def_level, pg.num_values, 4, &v))
-        for (int64_t i = 0; i < pg.num_values * 4; ++i) sum += v[i];
+      int64_t stored = 0;  // an OPTIONAL PLAIN page stores its non-NULL values only
+      if (PlainPageValues(pg.bytes->data(), (int64_t)pg.bytes->size(), max_def_level, pg.num_values, 4, &v, &stored))
+        for (int64_t i = 0; i < stored * 4; ++i) sum += v[i];
     }
   }
   return sum;

@@ -127,6 +127,7 @@ def test_chunked_scan_with_overlapped_allgather_one_rank(capi, ips, O):
             comm.fle_scan_allgather(enc, n, bw, capi.OP_LT, c, n_chunks, local, bvals, counts, full)
         comm.join()
         torch.cuda.synchronize()
+        comm.check()         # no waiter of a piece gave up
         ref_bm, ref_vals, ref_cnt = capi.fle_scan(enc, n, bw, capi.OP_LT, c)
         assert np.array_equal(words(full), O.fle_pred(enc_ref, n, bw, O.OP_LT, c))
         assert torch.equal(full, ref_bm) and torch.equal(local[:n // 64], ref_bm)
@@ -136,3 +137,54 @@ def test_chunked_scan_with_overlapped_allgather_one_rank(capi, ips, O):
             comm.fle_scan_allgather(enc, n - 2048, bw, capi.OP_LT, c, n_chunks, local, bvals, counts, full)
     finally:
         comm.close()
+
+
+def test_sharded_program_step_one_rank(capi, ips, O):
+    """ips_eval_program_chunks_allgather on a one-rank communicator: the Q6 conjunction over column
+    chunks cut into 8 exchange pieces (one C call per step: the plan's launches over all pieces, the
+    last operand signalling piece after piece, a waiter + all-gather per piece on the communicator's
+    stream) equals ips_eval_program on the contiguous columns and the oracle; also a tree whose last
+    operand cannot signal (an OR of two bitmaps: merge kernel) and one on an OPTIONAL column."""
+    q6 = ips.q6
+    n_pieces, piece = 8, 2048 * 9
+    n = n_pieces * piece
+    codes = [q6.codes_numpy(c, n) for c in range(3)]
+    chunks, encs = [], []
+    for c in range(3):
+        w = q6.COLUMNS[c][3]
+        enc = torch.from_numpy(O.fle_encode(codes[c], w).view(np.int64).copy()).cuda()
+        encs.append(enc)
+        wpp = piece // 64 * w
+        chunks.append(capi.Chunk([(enc[i * wpp:(i + 1) * wpp].clone(), piece, w) for i in range(n_pieces)]))
+    nodes, cols = q6.program(capi, encs)
+    ref = capi.eval_program(nodes, cols, n)
+    ops = {"GE": O.OP_GE, "LT": O.OP_LT}
+    exp = None
+    for col, op, k in q6.LEAVES:
+        leaf = O.fle_pred(O.fle_encode(codes[col], q6.COLUMNS[col][3]), n, q6.COLUMNS[col][3], ops[op], k)
+        exp = leaf if exp is None else (exp & leaf)
+    assert np.array_equal(words(ref), exp)
+    comm = capi.Comm(capi.comm_unique_id(), 1, 0)
+    try:
+        local = torch.zeros(n // 64, dtype=torch.int64, device="cuda")
+        full = torch.zeros(n // 64, dtype=torch.int64, device="cuda")
+        for _ in range(3):
+            comm.eval_program_chunks_allgather(nodes, chunks, local, full)
+        comm.join()
+        torch.cuda.synchronize()
+        comm.check()
+        assert torch.equal(full, ref) and torch.equal(local, ref)
+        # (A and B) or (C and D): the last step merges two bitmaps -- all pieces are released at once
+        L, AND, OR = capi.leaf, capi.and_node, capi.or_node
+        tree = [L(0, capi.OP_GE, 365), L(1, capi.OP_LT, 3), AND(), L(2, capi.OP_GE, 40), L(1, capi.OP_GE, 9), AND(), OR()]
+        ws = torch.empty(n // 8 + 4096, dtype=torch.uint8, device="cuda")
+        comm.eval_program_chunks_allgather(tree, chunks, local, full, workspace=ws)
+        comm.join()
+        torch.cuda.synchronize()
+        comm.check()
+        t = ((codes[0] >= 365) & (codes[1] < 3)) | ((codes[2] >= 40) & (codes[1] >= 9))
+        assert np.array_equal(words(full), np.packbits(t, bitorder="little").view(np.uint64))
+    finally:
+        comm.close()
+        for ch in chunks:
+            ch.close()
