@@ -47,6 +47,8 @@ SYMBOLS = [
     "ips_bitmap_and", "ips_bitmap_or", "ips_bitmap_fill", "ips_bitmap_count", "ips_bitmap_batch_counts",
     "ips_expand_workspace_bytes", "ips_bitmap_expand",
     "ips_eval_program", "ips_set_program_strategy", "ips_synth_splitmix_u32",
+    "ips_inset_open", "ips_dict_inset_open", "ips_inset_close", "ips_inset_size", "ips_fle_pred_inset",
+    "ips_fle_scan_inset", "ips_dict_scan_inset",
     "ips_chunk_open", "ips_chunk_close", "ips_chunk_num_rows", "ips_chunk_num_batches", "ips_chunk_num_pages",
     "ips_chunk_program_workspace_bytes", "ips_eval_program_chunks", "ips_chunk_fle_scan", "ips_chunk_dict_scan",
     "ips_chunk_plain_scan", "ips_chunk_select",
@@ -76,7 +78,7 @@ class TupleColumn(C.Structure):
 
 class Node(C.Structure):
     _fields_ = [("kind", C.c_int32), ("column", C.c_int32), ("op", C.c_int32),
-                ("n_consts", C.c_int32), ("consts", C.c_uint64 * 16)]
+                ("n_consts", C.c_int32), ("consts", C.c_uint64 * 16), ("inset", C.c_void_p)]
 
 
 _lib = None
@@ -594,6 +596,62 @@ def eval_program(nodes, cols, n_rows, bitmap=None, device=None, stream=None, wor
     _ck(lib().ips_eval_program(arr_n, len(nodes), arr_c, len(cols), C.c_int64(n_rows),
                                _ptr(bitmap), _ptr(workspace), _stream(stream)))
     return bitmap[:_words(n_rows)]
+
+
+# ---- IN lists of any length ---------------------------------------------------------------------
+class InSet:
+    """ips_inset: InSet(constants) for FLE values / codes, InSet(literals, dict_=d) for a dictionary column."""
+
+    def __init__(self, values, dict_=None):
+        self.h = C.c_void_p(0)
+        if dict_ is None:
+            v = np.ascontiguousarray(np.atleast_1d(values), dtype=np.uint64)
+            _ck(lib().ips_inset_open(v.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(len(v)), C.byref(self.h)))
+        else:
+            v = np.ascontiguousarray(np.atleast_1d(values), dtype=NP_TYPES[dict_.type])
+            _ck(lib().ips_dict_inset_open(dict_.h, v.ctypes.data_as(C.c_void_p), C.c_int64(len(v)), C.byref(self.h)))
+        lib().ips_inset_size.restype = C.c_int64
+        lib().ips_inset_size.argtypes = [C.c_void_p]
+        self.size = int(lib().ips_inset_size(self.h))
+
+    def close(self):
+        if self.h:
+            lib().ips_inset_close(self.h)
+            self.h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fle_pred_inset(enc, n_rows, bw, inset, bitmap=None, stream=None):
+    if bitmap is None:
+        bitmap = torch.empty(max(_words(n_rows), 2), dtype=torch.int64, device=enc.device)
+    _ck(lib().ips_fle_pred_inset(_ptr(enc), C.c_int64(n_rows), bw, inset.h, _ptr(bitmap), _stream(stream)))
+    return bitmap[:_words(n_rows)]
+
+
+def fle_scan_inset(enc, n_rows, bw, inset, outputs=None, stream=None):
+    bitmap, bvals, counts = outputs or alloc_scan_outputs(n_rows, enc.device)
+    _ck(lib().ips_fle_scan_inset(_ptr(enc), C.c_int64(n_rows), bw, inset.h, _ptr(bitmap), _ptr(bvals), _ptr(counts),
+                                 _stream(stream)))
+    return bitmap[:_words(n_rows)], bvals, counts[:n_batches(n_rows)]
+
+
+def dict_scan_inset(dict_, codes_enc, n_rows, bw, inset, stream=None):
+    bitmap, bvals, counts = alloc_scan_outputs(n_rows, codes_enc.device, TORCH_SLOT[dict_.type])
+    _ck(lib().ips_dict_scan_inset(dict_.h, _ptr(codes_enc), C.c_int64(n_rows), bw, inset.h, _ptr(bitmap), _ptr(bvals),
+                                  _ptr(counts), _stream(stream)))
+    return bitmap[:_words(n_rows)], bvals, counts[:n_batches(n_rows)]
+
+
+def inset_leaf(column, inset):
+    n = Node()
+    n.kind, n.column, n.op, n.n_consts = NODE_LEAF, column, OP_IN, 0
+    n.inset = inset.h
+    return n
 
 
 # ---- column chunks as lists of pages ----------------------------------------------------------

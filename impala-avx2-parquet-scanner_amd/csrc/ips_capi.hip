@@ -736,10 +736,137 @@ int ips_dict_bit_width(int64_t num_entries) {
 ips_status ips_dict_translate(const ips_dict* dict, ips_op op, const void* literals,
                               int n_literals, ips_xl_kind* kind, ips_op* fle_op, uint64_t* codes,
                               int* n_codes) {
-  ips_status st = check_dict_call(dict, op, literals, n_literals, "ips_dict_translate");
-  if (st != IPS_OK) return st;
+  // (host-side only: any number of literals; the calls that put the codes into a kernel argument take
+  // up to IPS_MAX_IN_LIST, longer lists go through ips_dict_inset_open)
+  IPS_REQUIRE(dict != nullptr, "ips_dict_translate: NULL dictionary");
+  IPS_REQUIRE(op >= IPS_OP_EQ && op <= IPS_OP_IN, "ips_dict_translate: bad op %d", (int)op);
+  IPS_REQUIRE(literals != nullptr && n_literals >= 1, "ips_dict_translate: no literals");
+  IPS_REQUIRE(op == IPS_OP_IN || n_literals == 1, "ips_dict_translate: op takes exactly one literal");
   IPS_REQUIRE(kind && fle_op && codes && n_codes, "ips_dict_translate: NULL out pointer");
   return translate(dict, op, literals, n_literals, kind, fle_op, codes, n_codes);
+}
+
+// ---- IN sets of any length --------------------------------------------------------------------
+}  // extern "C"
+namespace ips {
+void inset_pred_args(const ips_inset* set, int bw, PredArgs* args, bool* always_false) {
+  memset(args, 0, sizeof(*args));
+  const uint64_t limit = bw >= 32 ? 0xFFFFFFFFull : ((1ull << bw) - 1ull);
+  const int64_t fit = std::upper_bound(set->members.begin(), set->members.end(), (uint32_t)limit) - set->members.begin();
+  *always_false = fit == 0;
+  args->op = IPS_OP_IN;
+  args->n_consts = 1 << 30;  // (the launchers pick the membership table for codes of up to 16 bits)
+  args->in_table = set->d_table;
+  args->in_list = set->d_list;
+  args->in_list_n = (int32_t)fit;
+}
+static ips_status inset_create(std::vector<uint32_t>& members, ips_inset** out) {
+  std::sort(members.begin(), members.end());
+  members.erase(std::unique(members.begin(), members.end()), members.end());
+  ips_inset* s = new ips_inset();
+  s->members.swap(members);
+  s->d_table = nullptr;
+  s->d_list = nullptr;
+  std::vector<uint32_t> table(2048, 0u);
+  for (uint32_t c : s->members)
+    if (c < 65536u) table[c >> 5] |= 1u << (c & 31u);
+  const size_t list_bytes = (s->members.empty() ? 1 : s->members.size()) * sizeof(uint32_t);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_table), 2048 * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_list), list_bytes);
+  if (e == hipSuccess) e = hipMemcpy(s->d_table, table.data(), 2048 * sizeof(uint32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !s->members.empty())
+    e = hipMemcpy(s->d_list, s->members.data(), s->members.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (s->d_table) (void)hipFree(s->d_table);
+    if (s->d_list) (void)hipFree(s->d_list);
+    delete s;
+    return hip_fail(e, "ips_inset_open");
+  }
+  *out = s;
+  return IPS_OK;
+}
+}  // namespace ips
+extern "C" {
+
+ips_status ips_inset_open(const uint64_t* consts, int64_t n_consts, ips_inset** set) {
+  IPS_REQUIRE(set != nullptr && n_consts >= 0 && (n_consts == 0 || consts), "ips_inset_open: bad argument");
+  std::vector<uint32_t> members;
+  members.reserve((size_t)n_consts);
+  for (int64_t i = 0; i < n_consts; ++i)
+    if (consts[i] <= 0xFFFFFFFFull) members.push_back((uint32_t)consts[i]);  // (an FLE value has at most 32 bits)
+  return inset_create(members, set);
+}
+
+ips_status ips_dict_inset_open(const ips_dict* dict, const void* literals, int64_t n_literals, ips_inset** set) {
+  IPS_REQUIRE(dict != nullptr && set != nullptr && n_literals >= 0 && (n_literals == 0 || literals),
+              "ips_dict_inset_open: bad argument");
+  // DictDecoder<T>::In's translation (dict-encoding.h:523-541): the codes of the literals that are entries
+  std::vector<uint32_t> members;
+  const int64_t kPiece = 4096;
+  std::vector<uint64_t> codes((size_t)kPiece);
+  const uint8_t* lit = reinterpret_cast<const uint8_t*>(literals);
+  for (int64_t i = 0; i < n_literals; i += kPiece) {
+    const int n = (int)std::min<int64_t>(kPiece, n_literals - i);
+    ips_xl_kind kind; ips_op fle_op; int n_codes = 0;
+    translate(dict, IPS_OP_IN, lit + (size_t)i * (size_t)dict->elem, n, &kind, &fle_op, codes.data(), &n_codes);
+    for (int j = 0; j < n_codes; ++j) members.push_back((uint32_t)codes[(size_t)j]);
+  }
+  return inset_create(members, set);
+}
+
+ips_status ips_inset_close(ips_inset* set) {
+  if (!set) return IPS_OK;
+  if (set->d_table) (void)hipFree(set->d_table);
+  if (set->d_list) (void)hipFree(set->d_list);
+  delete set;
+  return IPS_OK;
+}
+
+int64_t ips_inset_size(const ips_inset* set) { return set ? (int64_t)set->members.size() : -1; }
+
+ips_status ips_fle_pred_inset(const void* d_enc, int64_t n_rows, int bit_width, const ips_inset* set,
+                              uint64_t* d_bitmap, ips_stream stream) {
+  if (!check_fle_common(d_enc, n_rows, bit_width, "ips_fle_pred_inset")) return IPS_ERR_INVALID_ARG;
+  IPS_REQUIRE(set != nullptr, "ips_fle_pred_inset: NULL set");
+  IPS_REQUIRE(n_rows == 0 || (d_bitmap && aligned16(d_bitmap)), "ips_fle_pred_inset: bitmap NULL or misaligned");
+  if (n_rows == 0) return IPS_OK;
+  PredArgs args;
+  bool none = false;
+  inset_pred_args(set, bit_width, &args, &none);
+  if (none) return launch_bitmap_fill(d_bitmap, n_rows, 0, S(stream));
+  return launch_fle_pred(bit_width, reinterpret_cast<const uint64_t*>(d_enc), n_rows, args,
+                         reinterpret_cast<uint32_t*>(d_bitmap), S(stream));
+}
+
+ips_status ips_fle_scan_inset(const void* d_enc, int64_t n_rows, int bit_width, const ips_inset* set,
+                              uint64_t* d_bitmap, uint32_t* d_batch_values, uint32_t* d_batch_counts,
+                              ips_stream stream) {
+  if (!check_fle_common(d_enc, n_rows, bit_width, "ips_fle_scan_inset")) return IPS_ERR_INVALID_ARG;
+  IPS_REQUIRE(set != nullptr, "ips_fle_scan_inset: NULL set");
+  IPS_REQUIRE(n_rows == 0 || (d_bitmap && aligned16(d_bitmap) && d_batch_values && aligned16(d_batch_values) && d_batch_counts),
+              "ips_fle_scan_inset: output NULL or misaligned");
+  if (n_rows == 0) return IPS_OK;
+  PredArgs args;
+  bool none = false;
+  inset_pred_args(set, bit_width, &args, &none);
+  return scan_common(d_enc, n_rows, bit_width, args, none ? kAllFalse : kEvaluate, d_bitmap, d_batch_values,
+                     d_batch_counts, 0, nullptr, 0, nullptr, S(stream));
+}
+
+ips_status ips_dict_scan_inset(const ips_dict* dict, const void* d_codes_enc, int64_t n_rows, int bit_width,
+                               const ips_inset* set, uint64_t* d_bitmap, void* d_batch_values,
+                               uint32_t* d_batch_counts, ips_stream stream) {
+  IPS_REQUIRE(dict != nullptr && set != nullptr, "ips_dict_scan_inset: NULL dictionary / set");
+  if (!check_fle_common(d_codes_enc, n_rows, bit_width, "ips_dict_scan_inset")) return IPS_ERR_INVALID_ARG;
+  IPS_REQUIRE(bit_width <= 16, "ips_dict_scan_inset: code width %d > 16", bit_width);
+  IPS_REQUIRE(n_rows == 0 || (d_bitmap && aligned16(d_bitmap) && d_batch_values && aligned16(d_batch_values) && d_batch_counts),
+              "ips_dict_scan_inset: output NULL or misaligned");
+  if (n_rows == 0) return IPS_OK;
+  PredArgs args;
+  bool none = false;
+  inset_pred_args(set, bit_width, &args, &none);
+  return scan_common(d_codes_enc, n_rows, bit_width, args, none ? kAllFalse : kEvaluate, d_bitmap, d_batch_values,
+                     d_batch_counts, dict->slot, dict->d_entries, (uint32_t)dict->n, nullptr, S(stream));
 }
 
 ips_status ips_dict_pred(const ips_dict* dict, const void* d_codes_enc, int64_t n_rows,

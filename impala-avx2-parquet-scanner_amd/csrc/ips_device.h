@@ -52,6 +52,13 @@ struct PredArgs {
   uint32_t* done;
   int32_t done_page0;  // page index of blockIdx.y == 0 in 'done' (the first page of the launch's run)
   uint32_t done_epoch; // the value a complete page's flag takes in this step
+  // IN over an ips_inset (any number of members): the 65536-bit membership table of the members
+  // < 2^16 (codes of up to 16 bits look themselves up) and, for wider columns, the ascending member
+  // list, of which the first in_list_n fit the column's width.  NULL: the list in consts[]
+  const uint32_t* in_table;
+  const uint32_t* in_list;
+  int32_t in_list_n;
+  int32_t reserved2;
   uint32_t consts[256];
 };
 
@@ -293,6 +300,7 @@ __device__ __forceinline__ uint32_t pred_from_lds(const uint32_t* lds32, int w, 
     return a.join == 1 ? (r1 & r2) : (r1 | r2);
   }
   if (a.op != 5) return pred_single_from_lds(lds32, w, lane, a.op, a.consts[0]);
+  if (a.in_list) return pred_in_from_lds(lds32, w, lane, a.in_list, a.in_list_n);
   return pred_in_from_lds(lds32, w, lane, a.consts, a.n_consts);
 }
 

@@ -67,6 +67,11 @@ struct InTable {
 
 template <int W>
 __device__ __forceinline__ void in_table_build(uint32_t* table, const PredArgs& args) {
+  if (args.in_table != nullptr) {  // an ips_inset: its table's first 2^W bits (members >= 2^W match no code of W bits)
+    for (int i = threadIdx.x; i < InTable<W>::kDwords; i += kThreads) table[i] = args.in_table[i];
+    __syncthreads();
+    return;
+  }
   for (int i = threadIdx.x; i < InTable<W>::kDwords; i += kThreads) table[i] = 0u;
   __syncthreads();
   for (int j = threadIdx.x; j < args.n_consts; j += kThreads) {
@@ -653,7 +658,8 @@ __device__ __forceinline__ void fle_pred_body(const uint64_t* __restrict__ enc, 
       planes_from_lds<W>(lds32, lane, p);
       sel = pred_in_from_regs<W>(p, args.consts, args.n_consts);
     } else {
-      sel = pred_in_from_lds(lds32, W, lane, args.consts, args.n_consts);
+      sel = args.in_list ? pred_in_from_lds(lds32, W, lane, args.in_list, args.in_list_n)
+                           : pred_in_from_lds(lds32, W, lane, args.consts, args.n_consts);
     }
     uint32_t bm = finish_bitmap_dword(sel, tile, lane, n_rows);
     const int64_t d = tile * 64 + lane;
@@ -900,7 +906,8 @@ __device__ __forceinline__ void fle_leaf_body(const uint64_t* __restrict__ enc, 
         planes_from_lds<W>(lds32, lane, p);
         sel = pred_in_from_regs<W>(p, args.consts, args.n_consts);
       } else {
-        sel = pred_in_from_lds(lds32, W, lane, args.consts, args.n_consts);
+        sel = args.in_list ? pred_in_from_lds(lds32, W, lane, args.in_list, args.in_list_n)
+                           : pred_in_from_lds(lds32, W, lane, args.consts, args.n_consts);
       }
       uint32_t bm = bitrev32(sel);
       const int64_t valid = n_sub - ((b0 + (int64_t)k * kBlocksPerTile) * 64 + (int64_t)lane * 32);

@@ -19,7 +19,19 @@ struct ips_dict {
   void* d_entries;              // n entries of 'slot' bytes (int8/int16 sign-extended to int32)
 };
 
+// An IN list of any length (FleDecoder::In / DictDecoder::In take a vector, fle-encoding.h:8236-8313,
+// dict-encoding.h:523-541; a dictionary holds up to 40000 codes): resident on the device as the
+// 65536-bit membership table of the members below 2^16 and as the ascending list of all members.
+struct ips_inset {
+  std::vector<uint32_t> members;  // ascending, distinct (host copy: how many fit a width)
+  uint32_t* d_table;              // 2048 dwords
+  uint32_t* d_list;               // members.size() dwords (at least one)
+};
+
 namespace ips {
+
+// the IN predicate over 'set' on a column of bw bits: *always_false when no member fits the width
+void inset_pred_args(const ips_inset* set, int bw, PredArgs* args, bool* always_false);
 
 // Outcome of comparing against constants that do not fit in bw bits (the
 // reference is inconsistent there; the build defines it by the unsigned SQL meaning).

@@ -586,6 +586,11 @@ ips_status emit_item(const ChainItem& it, int combine, const ips_column* cols, i
     args.op = it.a->op;
     args.n_consts = it.a->n_consts;
     for (int j = 0; j < it.a->n_consts; ++j) args.consts[j] = (uint32_t)it.a->consts[j];
+    if (it.a->inset) {  // an IN list of any length (ips_inset)
+      bool none = false;
+      inset_pred_args(it.a->inset, c.bit_width, &args, &none);
+      if (none) { args.op = IPS_OP_LT; args.n_consts = 1; args.consts[0] = 0u; args.in_table = nullptr; args.in_list = nullptr; }
+    }
     args.combine = combine;
     if (it.b) {
       args.join = it.join;
@@ -812,7 +817,7 @@ extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const
   memset(&prog, 0, sizeof(prog));
   prog.n_nodes = n_nodes;
   int depth = 0, max_depth = 0, n_leaves = 0;
-  bool any_nullable = false;
+  bool any_nullable = false, any_inset = false;
   const void* last_staged = nullptr;
   for (int i = 0; i < n_nodes; ++i) {
     const ips_node& nd = nodes[i];
@@ -822,8 +827,11 @@ extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const
       IPS_REQUIRE(n_leaves < kMaxLeaves, "ips_eval_program: more than %d leaves", kMaxLeaves);
       IPS_REQUIRE(nd.column >= 0 && nd.column < n_cols, "ips_eval_program: node %d: bad column", i);
       IPS_REQUIRE(nd.op >= IPS_OP_EQ && nd.op <= IPS_OP_IN, "ips_eval_program: node %d: bad op", i);
-      IPS_REQUIRE(nd.n_consts >= 1 && nd.n_consts <= 16 && (nd.op == IPS_OP_IN || nd.n_consts == 1),
+      IPS_REQUIRE(nd.inset || (nd.n_consts >= 1 && nd.n_consts <= 16 && (nd.op == IPS_OP_IN || nd.n_consts == 1)),
                   "ips_eval_program: node %d: bad constant count", i);
+      IPS_REQUIRE(!nd.inset || (nd.op == IPS_OP_IN && cols[nd.column].encoding == IPS_COL_FLE && nd.n_consts >= 0 && nd.n_consts <= 16),
+                  "ips_eval_program: node %d: a set belongs to an IN leaf on an FLE column", i);
+      any_inset = any_inset || nd.inset != nullptr;
       const ips_column& c = cols[nd.column];
       IPS_REQUIRE(n_rows == 0 || (c.d_data && aligned16(c.d_data)),
                   "ips_eval_program: column %d: data NULL or misaligned", nd.column);
@@ -841,7 +849,7 @@ extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const
       if (c.encoding == IPS_COL_FLE) {
         IPS_REQUIRE(c.bit_width >= 1 && c.bit_width <= 32, "ips_eval_program: column %d: bit width", nd.column);
         const uint64_t limit = c.bit_width == 32 ? 0xFFFFFFFFull : ((1ull << c.bit_width) - 1ull);
-        for (int j = 0; j < nd.n_consts; ++j)
+        for (int j = 0; j < nd.n_consts && !nd.inset; ++j)
           IPS_REQUIRE(nd.consts[j] <= limit, "ips_eval_program: node %d: constant does not fit the bit width", i);
       } else {
         IPS_REQUIRE(c.encoding == IPS_COL_PLAIN, "ips_eval_program: column %d: bad encoding", nd.column);
@@ -909,7 +917,7 @@ extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const
           const ips_node* la = p.item.a;
           const ips_node* lb = p.item.b;
           const ips_column& c = cols[la->column];
-          ok = p.kind == 0 && c.encoding == IPS_COL_FLE && (i == 0 ? p.combine == 0 : p.combine != 0);
+          ok = p.kind == 0 && c.encoding == IPS_COL_FLE && (i == 0 ? p.combine == 0 : p.combine != 0) && !la->inset;
           if (!ok) break;
           widths[i] = c.bit_width;
           memset(&ops[i], 0, sizeof(ChainOp));
@@ -945,8 +953,8 @@ extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const
                       reinterpret_cast<uint8_t*>(d_workspace), reinterpret_cast<hipStream_t>(stream));
     }
   }
-  if (any_nullable) {
-    set_error("ips_eval_program: OPTIONAL columns are evaluated by the per-operand plan only");
+  if (any_nullable || any_inset) {
+    set_error("ips_eval_program: OPTIONAL columns and IN sets are evaluated by the per-operand plan only");
     return IPS_ERR_UNSUPPORTED;
   }
   return launch_program(prog, n_rows, reinterpret_cast<uint32_t*>(d_bitmap),
@@ -993,6 +1001,12 @@ ips_status emit_item_chunk(const ChainItem& it, int combine, const ips_chunk* co
       PredArgs args;
       run_pred_args(run.bit_width, it.a->op, it.a->consts, it.a->n_consts, it.b ? it.join : 0, it.b ? it.b->op : 0,
                     it.b ? it.b->consts[0] : 0, combine, &args);
+      if (it.a->inset) {  // an IN list of any length (ips_inset); no member below 2^width: LT 0 = nothing
+        bool none = false;
+        inset_pred_args(it.a->inset, run.bit_width, &args, &none);
+        args.combine = combine;
+        if (none) { args.op = IPS_OP_LT; args.n_consts = 1; args.consts[0] = 0u; args.in_table = nullptr; args.in_list = nullptr; }
+      }
       ips_status st;
       if (done) {
         args.done = done;
@@ -1038,8 +1052,10 @@ ips_status check_chunk_program(const ips_node* nodes, int n_nodes, const ips_chu
     if (nd.kind == IPS_NODE_LEAF) {
       IPS_REQUIRE(nd.column >= 0 && nd.column < n_chunks, "ips_eval_program_chunks: node %d: bad column", i);
       IPS_REQUIRE(nd.op >= IPS_OP_EQ && nd.op <= IPS_OP_IN, "ips_eval_program_chunks: node %d: bad op", i);
-      IPS_REQUIRE(nd.n_consts >= 1 && nd.n_consts <= 16 && (nd.op == IPS_OP_IN || nd.n_consts == 1),
+      IPS_REQUIRE(nd.inset || (nd.n_consts >= 1 && nd.n_consts <= 16 && (nd.op == IPS_OP_IN || nd.n_consts == 1)),
                   "ips_eval_program_chunks: node %d: bad constant count", i);
+      IPS_REQUIRE(!nd.inset || (nd.op == IPS_OP_IN && chunks[nd.column]->encoding == IPS_COL_FLE && nd.n_consts >= 0 && nd.n_consts <= 16),
+                  "ips_eval_program_chunks: node %d: a set belongs to an IN leaf on an FLE column", i);
     } else {
       IPS_REQUIRE(nd.kind == IPS_NODE_AND || nd.kind == IPS_NODE_OR, "ips_eval_program_chunks: node %d: bad kind", i);
     }

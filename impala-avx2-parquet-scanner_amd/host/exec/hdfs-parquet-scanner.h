@@ -103,6 +103,7 @@ class HdfsParquetScanner {
   template <typename T>
   class ColumnReader : public BaseColumnReader {
    public:
+    ~ColumnReader() { if (in_set_) ips_inset_close(in_set_); }
     // ColumnReader::IntersectBitset, .cc:326-331 (the device twin is ips_bitmap_expand)
     static void IntersectBitset(SkipBitset& root_bitset, SkipBitset& sub_bitset) {
       int64_t j = -1;
@@ -164,8 +165,34 @@ class HdfsParquetScanner {
       memset(col, 0, sizeof(*col));
       memset(node, 0, sizeof(*node));
       node->kind = IPS_NODE_LEAF;
-      if (n_lits > 16) return false;
       if (max_def_level_ > 0 && !dict_decoder_) return false;  // the PLAIN branch has no NULL handling (.cc:346-348)
+      if (dict_decoder_ && op == IPS_OP_IN && n_lits > 16) {
+        // InOperate keeps a vector of any length (simple-predicates.h:195-205): the codes of the
+        // literals that are dictionary entries (dict-encoding.h:523-541) become a resident set, kept
+        // with the reader for as long as the same literals come back
+        const size_t bytes = (size_t)n_lits * sizeof(T);
+        if (!in_set_ || in_set_key_.size() != bytes || memcmp(in_set_key_.data(), lits, bytes) != 0) {
+          if (in_set_) ips_inset_close(in_set_);
+          in_set_ = nullptr;
+          if (!ips::ok(ips_dict_inset_open(dict_decoder_->handle(), lits, n_lits, &in_set_), "ips_dict_inset_open")) return false;
+          in_set_key_.assign((const uint8_t*)lits, (const uint8_t*)lits + bytes);
+        }
+        col->encoding = IPS_COL_FLE;
+        col->bit_width = dict_decoder_->code_bit_width();
+        col->d_data = dict_decoder_->codes()->device_blocks();
+        if (max_def_level_ > 0) {
+          if (!fle_def_levels_ || !fle_def_levels_->usable()) return false;
+          col->max_def_level = max_def_level_;
+          col->d_def_levels = fle_def_levels_->device_blocks();
+          col->def_bit_width = fle_def_levels_->bit_width();
+          col->n_data_rows = dict_decoder_->codes()->rows_in_buffer();
+        }
+        node->op = IPS_OP_IN;
+        node->n_consts = 0;
+        node->inset = in_set_;
+        return true;
+      }
+      if (n_lits > 16) return false;
       if (dict_decoder_) {
         ips_xl_kind kind; ips_op fle_op; int n_codes = 0;
         uint64_t codes[16];
@@ -361,6 +388,8 @@ class HdfsParquetScanner {
 
     std::unique_ptr<DictDecoder<T>> dict_decoder_;
     std::unique_ptr<FleDecoder> fle_def_levels_;
+    ips_inset* in_set_ = nullptr;        // the long IN list last lowered on this column (LowerLeaf)
+    std::vector<uint8_t> in_set_key_;
     uint8_t* data_ = nullptr;        // PLAIN: current position (the predicates start here)
     uint8_t* data_end_ = nullptr;
     uint8_t* plain_begin_ = nullptr;

@@ -794,6 +794,48 @@ static void TestAssembleRowsFused() {
 
 // ips_eval_program straight through the C-ABI from a plain C++ process: an OR of two conjunctions
 // needs a temporary bitmap next to d_bitmap (stream-ordered allocation inside the call).
+// InOperate with more literals than a program node or a kernel argument holds (the reference's In()
+// takes a vector of any length): the per-batch pattern and the fused one agree with the row model.
+static void TestLongInList() {
+  const int n = 20011;
+  std::vector<int32_t> c0(n);
+  DictEncoder<int32_t> e0;
+  for (int i = 0; i < n; ++i) { c0[i] = (int32_t)(rnd() % 5000) * 3; e0.Put(c0[i]); }
+  std::vector<uint8_t> d0((size_t)e0.dict_encoded_size() + 8), data(1 << 18);
+  e0.WriteDict(d0.data());
+  const int len = e0.WriteData(data.data(), (int)data.size());
+  CHECK(len > 0);
+  std::vector<int32_t> lits;
+  for (int v = 0; v < 1200; ++v) lits.push_back(v * 7);  // 1200 literals, a third of them multiples of 3
+  std::vector<bool> member(15000 * 3, false);
+  for (int32_t v : lits) if (v % 3 == 0) member[(size_t)v] = true;
+  for (int pass = 0; pass < 2; ++pass) {
+    HdfsParquetScanner scanner;
+    CHECK(scanner.AddDictionaryColumn<int32_t>(d0.data(), e0.dict_encoded_size(), data.data(), len, n) == 0);
+    scanner.AddSimplePredicate(scanner.Own(new InOperate<int32_t>(0, lits)));
+    int64_t wrong = 0;
+    if (pass == 0) {
+      std::vector<uint64_t> words;
+      CHECK(scanner.EvalSimplePredicatesFused(n, &words));
+      for (int i = 0; i < n; ++i) wrong += (((words[(size_t)i >> 6] >> (i & 63)) & 1) != 0) != (bool)member[(size_t)c0[i]];
+    } else {
+      int64_t row = 0;
+      while (row < n) {
+        SkipBitset bs;
+        CHECK(scanner.EvalSimplePredicates(bs));
+        for (size_t i = 0; i < bs.size(); ++i) wrong += bs[i] != (bool)member[(size_t)c0[(size_t)row + i]];
+        row += (int64_t)bs.size();
+        if (bs.size() == 0) break;
+        scanner.SkipValue(0, (int)bs.size());  // (the predicates do not advance the row cursor, A.3)
+      }
+      CHECK(row == n);
+    }
+    if (wrong) fprintf(stderr, "TestLongInList: pass %d: %lld rows wrong\n", pass, (long long)wrong);
+    CHECK(wrong == 0);
+  }
+  CHECK(ips::sticky_status() == IPS_OK);
+}
+
 static void TestProgramWithTemporaryBitmap() {
   const int n = 70001;
   std::vector<uint32_t> a(n), b(n);
@@ -862,6 +904,7 @@ int main() {
   TestTruncatedPages();
   TestColumnChunkStream();
   TestAssembleRowsFused();
+  TestLongInList();
   CHECK(ips::sticky_status() == IPS_OK);
   printf("facade_test: %d checks, %d failed\n", g_checks, g_fail);
   return g_fail ? 1 : 0;

@@ -118,9 +118,21 @@ class FleDecoder {
       if (s_->usable && s_->rows > 0) {
         ++ips::stats().pred_launches;
         ips::DeviceBuffer bm((size_t)w->size() * 8);
-        if (ips::ok(ips_fle_pred(s_->enc.get(), s_->rows, s_->bw, op, consts, n,
-                                 bm.as<uint64_t>(), nullptr), "ips_fle_pred"))
-          bm.download(w->data(), w->size() * 8);
+        bool done = false;
+        if (op == IPS_OP_IN && n > IPS_MAX_IN_LIST) {
+          // In() takes a vector of any length (fle-encoding.h:8236-8313): beyond what a kernel argument
+          // holds the list becomes a resident set for this one whole-page evaluation
+          ips_inset* set = nullptr;
+          done = ips::ok(ips_inset_open(consts, n, &set), "ips_inset_open") &&
+                 ips::ok(ips_fle_pred_inset(s_->enc.get(), s_->rows, s_->bw, set, bm.as<uint64_t>(), nullptr),
+                         "ips_fle_pred_inset");
+          if (done) ips::ok(ips_stream_synchronize(nullptr), "ips_stream_synchronize");
+          ips_inset_close(set);
+        } else {
+          done = ips::ok(ips_fle_pred(s_->enc.get(), s_->rows, s_->bw, op, consts, n, bm.as<uint64_t>(), nullptr),
+                         "ips_fle_pred");
+        }
+        if (done) bm.download(w->data(), w->size() * 8);
       }
       words = w;
     }

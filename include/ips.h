@@ -65,6 +65,7 @@ typedef enum { IPS_XL_ALL_FALSE = 0, IPS_XL_ALL_TRUE = 1, IPS_XL_FLE = 2 } ips_x
 
 typedef void* ips_stream;
 typedef struct ips_dict ips_dict;
+typedef struct ips_inset ips_inset; /* an IN list of any length, resident on the device (below) */
 
 /* Rows per selection batch of the fused scan: each batch's selected values are written densely,
  * in row order, at d_batch_values + batch*IPS_BATCH_ROWS (the scanner hands row batches upstream,
@@ -236,10 +237,39 @@ ips_status ips_dict_encode(const void* d_values, int64_t n_rows, ips_type type, 
                            void* d_codes_enc, void* d_workspace, ips_stream stream);
 
 /* Literal -> code translation of DictDecoder<T>::Eq/Lt/Le/Gt/Ge/In, dict-encoding.h:461-541.
- * literals: n_literals values of the dictionary's type (host).  codes must hold n_literals. */
+ * literals: n_literals values of the dictionary's type (host), any number of them for IN.  codes
+ * must hold n_literals. */
 ips_status ips_dict_translate(const ips_dict* dict, ips_op op, const void* literals,
                               int n_literals, ips_xl_kind* kind, ips_op* fle_op,
                               uint64_t* codes, int* n_codes);
+
+/* ---- IN lists of any length ------------------------------------------------------------------- */
+/* FleDecoder::In / DictDecoder::In take a vector of any length (fle-encoding.h:8236-8313,
+ * dict-encoding.h:523-541; a dictionary holds up to 40000 codes).  The lists of up to
+ * IPS_MAX_IN_LIST constants that the calls above take travel in the kernel arguments; a longer one
+ * (or one that is used again and again: InOperate keeps its literals for the whole scan,
+ * simple-predicates.h:195-205) is made resident once as an ips_inset: the membership table of the
+ * members below 2^16 (codes of up to 16 bits look themselves up: one LDS read per row whatever the
+ * list's length) and the ascending member list (wider columns compare against it member by member;
+ * a column of w bits ignores members >= 2^w).  ips_inset_open / ips_dict_inset_open are synchronous
+ * (they upload); duplicates are dropped; an empty set selects nothing. */
+ips_status ips_inset_open(const uint64_t* consts, int64_t n_consts, ips_inset** set);
+/* the set of CODES of the literals that are dictionary entries: DictDecoder<T>::In's translation,
+ * dict-encoding.h:523-541, done once */
+ips_status ips_dict_inset_open(const ips_dict* dict, const void* literals, int64_t n_literals,
+                               ips_inset** set);
+ips_status ips_inset_close(ips_inset* set);
+int64_t ips_inset_size(const ips_inset* set); /* distinct members */
+/* ips_fle_pred / ips_fle_scan / ips_dict_scan with op IN over a set (a dictionary column's predicate
+ * alone is ips_fle_pred_inset on its codes) */
+ips_status ips_fle_pred_inset(const void* d_enc, int64_t n_rows, int bit_width, const ips_inset* set,
+                              uint64_t* d_bitmap, ips_stream stream);
+ips_status ips_fle_scan_inset(const void* d_enc, int64_t n_rows, int bit_width, const ips_inset* set,
+                              uint64_t* d_bitmap, uint32_t* d_batch_values, uint32_t* d_batch_counts,
+                              ips_stream stream);
+ips_status ips_dict_scan_inset(const ips_dict* dict, const void* d_codes_enc, int64_t n_rows,
+                               int bit_width, const ips_inset* set, uint64_t* d_bitmap,
+                               void* d_batch_values, uint32_t* d_batch_counts, ips_stream stream);
 
 /* DictDecoder<T>::Eq/Lt/Le/Gt/Ge/In on a REQUIRED column's data page, dict-encoding.h:461-541.
  * d_codes_enc: the FLE blocks of the page, i.e. the payload AFTER the 1-byte bit-width header
@@ -381,6 +411,8 @@ typedef struct {
   int32_t op;            /* leaf: ips_op (FLE: on codes/values; PLAIN: SQL semantics) */
   int32_t n_consts;      /* leaf: 1, or 1..16 for IN */
   uint64_t consts[16];   /* leaf: FLE constants, or PLAIN literal bit patterns */
+  const ips_inset* inset; /* leaf, op IPS_OP_IN on an FLE column: the list as a set of any length
+                            (ips_inset_open); n_consts / consts are then ignored.  NULL otherwise */
 } ips_node;
 
 /* How ips_eval_program evaluates a tree.  AUTO (the default) = PER_OPERAND: one launch of a

@@ -754,3 +754,73 @@ def test_dictionary_scan_dense_selections(capi, O, type_name, D, bw):
         dense2 = np.concatenate([svn[b * 2048: b * 2048 + scn[b]] for b in range(len(scn))])
         assert np.array_equal(dense2.astype(npt), vals[keep]), (D, bw, frac)
     dd.close()
+
+
+def test_in_sets_of_any_length(capi, O):
+    """IN lists beyond the 256 constants a kernel argument holds (FleDecoder::In / DictDecoder::In take
+    a vector of any length, fle-encoding.h:8236-8313, dict-encoding.h:523-541): K = 40000 on a w = 16
+    dictionary column (the reference's dictionary cap) through the predicate, the fused scan + gather
+    and a program leaf (REQUIRED and OPTIONAL), K = 3000 on raw FLE columns of 12 and 21 bits, an
+    empty set, members beyond the column's width -- against the oracle's In on the same list."""
+    rng = np.random.default_rng(77)
+    n = 150001
+    D = 40000                                             # the reference's dictionary cap (dict-encoding.h:157)
+    dict_vals = np.sort(rng.choice(np.arange(-10 ** 6, 10 ** 6), D, replace=False)).astype(np.int32)
+    codes = rng.integers(0, D, n).astype(np.uint32)
+    enc_h = O.fle_encode(codes, 16)
+    enc = dev_words(enc_h)
+    dd = capi.Dict(dict_vals.view(np.uint8), capi.T_INT32)
+    members = rng.choice(D, 39000, replace=False)
+    lits = np.concatenate([dict_vals[members], dict_vals[members[:500]], np.arange(500, dtype=np.int32) + 10 ** 7])
+    lits = lits.astype(np.int32)                          # 40000 literals: duplicates and ones that are no entries
+    s = capi.InSet(lits, dict_=dd)
+    assert len(lits) == 40000 and s.size == 39000
+    truth = np.isin(codes, members)
+    ref = O.fle_pred(enc_h, n, 16, O.OP_IN, np.sort(members).tolist())          # the oracle's In over 40000 codes
+    assert np.array_equal(bits_of(ref, n), truth)
+    assert np.array_equal(words(capi.fle_pred_inset(enc, n, 16, s)), ref)
+    bitmap, bvals, counts = capi.dict_scan_inset(dd, enc, n, 16, s)
+    assert np.array_equal(words(bitmap), ref)
+    assert np.array_equal(capi.batches_compact(bvals, counts, n).cpu().numpy(), dict_vals[codes[truth]])
+    # a program leaf: (codes IN set) AND (other < 9), then on an OPTIONAL column
+    other = rng.integers(0, 32, n).astype(np.uint32)
+    enc_o = dev_words(O.fle_encode(other, 5))
+    nodes = [capi.inset_leaf(0, s), capi.leaf(1, capi.OP_LT, 9), capi.and_node()]
+    got = capi.eval_program(nodes, [capi.fle_column(enc, 16), capi.fle_column(enc_o, 5)], n)
+    assert np.array_equal(bits_of(words(got), n), truth & (other < 9))
+    is_set = rng.random(n) >= 0.25
+    k = int(is_set.sum())
+    defs = dev_words(O.fle_encode(is_set.astype(np.uint32), 1))
+    enc_nn = dev_words(O.fle_encode(codes[is_set], 16))
+    ncol = capi.nullable_fle_column(defs, 1, 1, enc_nn, 16, ((k + 63) // 64) * 64)
+    got = capi.eval_program([capi.inset_leaf(0, s)], [ncol], n)
+    assert np.array_equal(bits_of(words(got), n), truth & is_set)
+    # the same leaf over a page list
+    cut = [50001, 33, 70000, n - 50001 - 33 - 70000]
+    pages, pos = [], 0
+    for m in cut:
+        pages.append((dev_words(O.fle_encode(codes[pos:pos + m], 16)), m, 16))
+        pos += m
+    chunk = capi.Chunk(pages)
+    got = capi.eval_program_chunks([capi.inset_leaf(0, s)], [chunk])
+    assert np.array_equal(words(got), ref)
+    chunk.close()
+    s.close()
+    dd.close()
+    # raw FLE columns: 12 bits (table) and 21 bits (member by member), members beyond the width ignored
+    for bw, K in ((12, 3000), (21, 600)):
+        vals = rng.integers(0, 1 << bw, 40003, dtype=np.uint64).astype(np.uint32)
+        e_h = O.fle_encode(vals, bw)
+        e = dev_words(e_h)
+        mem = rng.choice(1 << bw, K, replace=False).astype(np.uint64)
+        s = capi.InSet(np.concatenate([mem, np.array([1 << bw, (1 << 31) + 5, 1 << 40], np.uint64)]))
+        ref = O.fle_pred(e_h, len(vals), bw, O.OP_IN, np.sort(mem).tolist())
+        assert np.array_equal(words(capi.fle_pred_inset(e, len(vals), bw, s)), ref), bw
+        bitmap, bvals, counts = capi.fle_scan_inset(e, len(vals), bw, s)
+        assert np.array_equal(words(bitmap), ref), bw
+        assert np.array_equal(capi.batches_compact(bvals, counts, len(vals)).cpu().numpy().view(np.uint32),
+                              vals[np.isin(vals, mem.astype(np.uint32))]), bw
+        s.close()
+    empty = capi.InSet(np.zeros(0, np.uint64))
+    assert int(capi.fle_pred_inset(enc, n, 16, empty).abs().sum().item()) == 0
+    empty.close()
