@@ -15,7 +15,7 @@
     defined(IPS_SCAN_SMALL_LDS) || defined(IPS_SCAN_SMALL_LDS_MAX_W) || defined(IPS_ABLATE) ||          \
     defined(IPS_GATHER_WIDE) || defined(IPS_GATHER_MAX_4) || defined(IPS_QUADS) || defined(IPS_QUADS16) || \
     defined(IPS_PHASE_B_GROUP) || defined(IPS_NT_VALUE_STORE) || defined(IPS_DECODE_PACKED) ||          \
-    defined(IPS_EXP_ROUNDS) || defined(IPS_AUX_NT) || defined(IPS_PLAIN_ABLATE) || defined(IPS_MIN_SHARE) ||  \
+    defined(IPS_EXP_ROUNDS) || defined(IPS_AUX_NT) || defined(IPS_PLAIN_ABLATE) || defined(IPS_MIN_SHARE) || defined(IPS_PLAIN_DENSE8) ||  \
     defined(IPS_WINDOW_ABLATE)
 #error "development switches need -DIPS_DEV_KNOBS (the default library has none)"
 #endif
@@ -71,6 +71,9 @@
 #endif
 #ifndef IPS_DECODE_PACKED
 #define IPS_DECODE_PACKED 1         // dictionary decode of <= 16-bit codes from the lane-packed image
+#endif
+#ifndef IPS_PLAIN_DENSE8
+#define IPS_PLAIN_DENSE8 16u        // 8-byte PLAIN tiles (1024 rows) take the dense compaction from rows / this on
 #endif
 #ifndef IPS_PLAIN_ABLATE
 #define IPS_PLAIN_ABLATE 0  // timing only, RESULTS ARE WRONG: 1 drops the PLAIN scan's value stores, 2 the whole materialisation

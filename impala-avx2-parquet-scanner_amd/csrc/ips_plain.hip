@@ -51,7 +51,8 @@ __device__ __forceinline__ T slot_value(S raw) {
 constexpr int kPlainTileBytes = 8192;
 constexpr int kPlainLaneBytes = kPlainTileBytes / kWave;           // 128
 constexpr int kPlainLaneStride = kPlainLaneBytes + 16;             // 144
-constexpr int kPlainImageBytes = kWave * kPlainLaneStride;         // 9216
+constexpr int kPlainImageBytes = kWave * kPlainLaneStride;         // 9216 (also holds the 2048 + 64 dwords of the dense compaction image)
+static_assert(kPlainImageBytes >= (2048 + 64) * 4, "the padded compaction image fits the tile image");
 constexpr int kPlainListMax = 512;
 constexpr int kPlainWaveBytes = kPlainImageBytes + 2 * kPlainListMax;  // 10240
 constexpr int kPlainLoads = kPlainTileBytes / (16 * kWave);        // 8 x 16 bytes per lane
@@ -161,6 +162,42 @@ __device__ __forceinline__ void plain_materialise(const uint8_t* lds, uint16_t* 
 #pragma unroll 1  // (unrolled it takes 64 more registers and the kernel half its waves)
     for (uint32_t i = lane; i < (uint32_t)G::RT; i += kWave)
       dst[i] = *reinterpret_cast<const S*>(lds + (i / (uint32_t)G::R) * kPlainLaneStride + (i % (uint32_t)G::R) * sizeof(S));
+    return;
+  }
+  if (count > (sizeof(S) == 8 ? (uint32_t)G::RT / IPS_PLAIN_DENSE8 : (uint32_t)G::RT / 4u)) {
+    // Dense tiles (more than a quarter of the rows selected, wave-uniform): the lane takes its 128
+    // bytes into registers, every lane appends the dwords of its selected rows behind those of the
+    // lanes before it in the (padded) compaction image, and the image leaves as whole 16-byte
+    // stores -- the FLE scan's dense path.  The index list would need three windows of up to 32
+    // ballot-controlled rounds each at 60 % (int32 twin of configs[1]: 397 -> 3xx us).
+    uint32_t v[32];
+#pragma unroll
+    for (int k = 0; k < kPlainLoads; ++k) {
+      const u32x4 q = *reinterpret_cast<const u32x4*>(lds + lane * kPlainLaneStride + 16 * k);
+      v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+    }
+    constexpr uint32_t DPS = sizeof(S) / 4;  // dwords per slot
+    uint32_t md = m;                          // one mask bit per dword of the lane
+    if (DPS == 2) {                           // bit j -> bits 2j, 2j + 1
+      uint32_t x = m & 0xFFFFu;
+      x = (x | (x << 8)) & 0x00FF00FFu;
+      x = (x | (x << 4)) & 0x0F0F0F0Fu;
+      x = (x | (x << 2)) & 0x33333333u;
+      x = (x | (x << 1)) & 0x55555555u;
+      md = x | (x << 1);
+    }
+    wave_lds_fence();  // every lane has its rows in registers: the image becomes the compaction image
+    uint32_t* lds32 = reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(lds));
+    compact_lane_values(lds32, md, P * DPS, v);
+    wave_lds_fence();
+    const uint32_t n_dw = count * DPS;
+    uint32_t* out = reinterpret_cast<uint32_t*>(dst);
+    if ((reinterpret_cast<uintptr_t>(out) & 15u) == 0u) {  // (wave-uniform: the second tile of an 8-byte batch starts anywhere)
+      store_compacted(lds32, n_dw, out, lane);
+    } else {
+      for (uint32_t e = lane; e < n_dw; e += kWave) out[e] = lds32[compact_dw(e)];
+    }
+    wave_lds_fence();
     return;
   }
   uint32_t pos = P;
@@ -280,8 +317,10 @@ __device__ __forceinline__ void plain_tile_body(const S* __restrict__ page, int6
   if constexpr (PAGED) window_flush(*win, carry, lit.combine);
 }
 
+// (four waves per SIMD is what the 40-KiB workgroups allow; the dense path's 32 row registers must
+// not cost the scan one of them)
 template <typename T, typename S, bool SCAN>
-__global__ __launch_bounds__(kThreads) void plain_tile_kernel(const S* __restrict__ page, int64_t n_rows, int op,
+__global__ __launch_bounds__(kThreads, 4) void plain_tile_kernel(const S* __restrict__ page, int64_t n_rows, int op,
                                                               PlainLit<T> lit, uint32_t* __restrict__ bitmap32,
                                                               S* __restrict__ batch_values,
                                                               uint32_t* __restrict__ batch_counts) {
@@ -289,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void plain_tile_kernel(const S* __restric
 }
 
 template <typename T, typename S, bool SCAN>
-__global__ __launch_bounds__(kThreads) void plain_tile_pages_kernel(const ChunkPage* __restrict__ pages, int64_t chunk_rows,
+__global__ __launch_bounds__(kThreads, 4) void plain_tile_pages_kernel(const ChunkPage* __restrict__ pages, int64_t chunk_rows,
                                                                     int op, PlainLit<T> lit, uint32_t* __restrict__ bitmap32,
                                                                     S* __restrict__ batch_values,
                                                                     uint32_t* __restrict__ batch_counts) {
@@ -416,7 +455,7 @@ ips_status launch_plain_scan_pages(int type, const ChunkPage* d_pages, int n_pag
 constexpr uint32_t kPlainSelectStreamMin = 64;  // selected rows per 2048-row batch (3 %)
 
 template <typename S>
-__global__ __launch_bounds__(kThreads) void plain_select_kernel(
+__global__ __launch_bounds__(kThreads, 4) void plain_select_kernel(
     const S* __restrict__ page, int64_t n_rows, const uint32_t* __restrict__ bitmap32,
     S* __restrict__ batch_values, uint32_t* __restrict__ batch_counts) {
   using G = PlainGeom<S>;
