@@ -85,17 +85,20 @@ static ips_status launch_decode_w(int out_width, int gather, const uint64_t* enc
       static const bool shared_off = dev_env("IPS_NO_SHARED_DICT") != nullptr;  // dev switch for A/B runs
       if (!shared_off && (size_t)dict_entries * (size_t)gather > (size_t)kDecodeDictLdsBytes && n_rows >= (1 << 20)) {
         // as many waves as leave room for the whole dictionary; the largest ones (e.g. 40000 int32
-        // entries) go with four waves and keep their tail in L2
+        // entries = 160000 bytes) go with EIGHT waves, three quarters of the entries in LDS and the tail
+        // gathered from L2 with all of a sub-tile's tail loads in flight together (D = 40000 int32:
+        // 606 us with four waves and a tenth in L2, 559 with the batched tail loads, 391 with eight
+        // waves, 570 with sixteen; int64: 957 -> 864 us)
         if (gather == 4) {
           if (shared_dict_fits<W, 4>(16, dict_entries)) return launch_decode_shared<W, 4, 16>(enc, n_rows, out, dict, dict_entries, bad_index, s);
           if (shared_dict_fits<W, 4>(8, dict_entries)) return launch_decode_shared<W, 4, 8>(enc, n_rows, out, dict, dict_entries, bad_index, s);
           if (shared_dict_fits<W, 4>(4, dict_entries)) return launch_decode_shared<W, 4, 4>(enc, n_rows, out, dict, dict_entries, bad_index, s);
-          return launch_decode_shared<W, 4, 4, true>(enc, n_rows, out, dict, dict_entries, bad_index, s);
+          return launch_decode_shared<W, 4, 8, true>(enc, n_rows, out, dict, dict_entries, bad_index, s);
         } else if (gather == 8) {
           if (shared_dict_fits<W, 8>(16, dict_entries)) return launch_decode_shared<W, 8, 16>(enc, n_rows, out, dict, dict_entries, bad_index, s);
           if (shared_dict_fits<W, 8>(8, dict_entries)) return launch_decode_shared<W, 8, 8>(enc, n_rows, out, dict, dict_entries, bad_index, s);
           if (shared_dict_fits<W, 8>(4, dict_entries)) return launch_decode_shared<W, 8, 4>(enc, n_rows, out, dict, dict_entries, bad_index, s);
-          return launch_decode_shared<W, 8, 4, true>(enc, n_rows, out, dict, dict_entries, bad_index, s);
+          return launch_decode_shared<W, 8, 8, true>(enc, n_rows, out, dict, dict_entries, bad_index, s);
         }
       }
     }

@@ -1533,6 +1533,46 @@ __global__ __launch_bounds__(BW * kWave, SHARED ? 1 : IPS_MIN_WAVES_PER_EU) void
         const int pos0 = 31 - 4 * q;
         const int grp = (pos0 % R) / 4;     // registers 4 grp .. 4 grp + 3
         const uint32_t fsh = (uint32_t)(R * (pos0 / R));
+        if constexpr (kSharedDict && TAIL) {
+          // A dictionary whose tail stays in L2: with one wave per SIMD nothing but the wave's own
+          // loads in flight hides an L2 round trip, and a look-up that falls into the tail under a
+          // branch of its own makes the wave wait 32 times per sub-tile.  All 32 codes are looked up in
+          // the LDS part first, then the tail loads of the whole sub-tile are issued together.
+          uint32_t xs[8][4];
+          GT ys[8][4];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int src = 8 * k + (lane >> 3);
+            const u32x4 t = *reinterpret_cast<const u32x4*>(lds8 + src * kStride + 16 * grp);
+            xs[k][0] = (t.w >> fsh) & kMask; xs[k][1] = (t.z >> fsh) & kMask;
+            xs[k][2] = (t.y >> fsh) & kMask; xs[k][3] = (t.x >> fsh) & kMask;
+            const int64_t valid = n_rows - (row_base + 4 * (64 * k + lane));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (e >= valid) xs[k][e] = 0u;                       // (rows that do not exist: entry 0, never stored)
+              else if (xs[k][e] >= dict_entries) { bad = 1; xs[k][e] = 0u; }
+              ys[k][e] = dict_dyn[xs[k][e] < lds_entries ? xs[k][e] : 0u];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (xs[k][e] >= lds_entries) ys[k][e] = dict[xs[k][e]];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int64_t row = row_base + 4 * (64 * k + lane);
+            const int64_t valid = n_rows - row;
+            if (valid >= 4) {
+              const u32x4 o = {(uint32_t)ys[k][0], (uint32_t)ys[k][1], (uint32_t)ys[k][2], (uint32_t)ys[k][3]};
+              IPS_STREAM_STORE16(dst_all + row, o);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (e < valid) dst_all[row + e] = ys[k][e];
+            }
+          }
+        } else
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int src = 8 * k + (lane >> 3);
@@ -1564,6 +1604,40 @@ __global__ __launch_bounds__(BW * kWave, SHARED ? 1 : IPS_MIN_WAVES_PER_EU) void
         const int pos0 = 31 - 2 * u;
         const int reg_lo = (pos0 - 1) % R;  // even register of the pair
         const uint32_t fsh = (uint32_t)(R * (pos0 / R));
+        if constexpr (kSharedDict && TAIL) {  // (as above: LDS look-ups first, the tail's loads together)
+          uint32_t xs[16][2];
+          GT ys[16][2];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int src = 4 * k + (lane >> 4);
+            const u32x2 t = *reinterpret_cast<const u32x2*>(lds8 + src * kStride + 4 * reg_lo);
+            xs[k][0] = (t.y >> fsh) & kMask;
+            xs[k][1] = (t.x >> fsh) & kMask;
+            const int64_t valid = n_rows - (row_base + 2 * (64 * k + lane));
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              if (e >= valid) xs[k][e] = 0u;
+              else if (xs[k][e] >= dict_entries) { bad = 1; xs[k][e] = 0u; }
+              ys[k][e] = dict_dyn[xs[k][e] < lds_entries ? xs[k][e] : 0u];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+              if (xs[k][e] >= lds_entries) ys[k][e] = dict[xs[k][e]];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int64_t row = row_base + 2 * (64 * k + lane);
+            const int64_t valid = n_rows - row;
+            if (valid >= 2) {
+              const u32x4 o = {(uint32_t)ys[k][0], (uint32_t)((uint64_t)ys[k][0] >> 32), (uint32_t)ys[k][1], (uint32_t)((uint64_t)ys[k][1] >> 32)};
+              IPS_STREAM_STORE16(dst_all + row, o);
+            } else if (valid == 1) {
+              dst_all[row] = ys[k][0];
+            }
+          }
+        } else
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
           const int src = 4 * k + (lane >> 4);
