@@ -196,14 +196,14 @@ __device__ __forceinline__ void window_emit_quad(const BitmapWindow& w, WindowCa
 // dword aligned (neighbouring waves stream neighbouring bytes), else ONE contiguous share, so that
 // the carry above covers all but the share's two ends.
 struct TileShare { int64_t first, step, end; };
-__device__ __forceinline__ TileShare tile_share(const BitmapWindow& w, int64_t tiles, int64_t wave_index, int64_t n_waves) {
+__device__ __forceinline__ TileShare tile_share(const BitmapWindow& w, int64_t tiles, int64_t wave_index, int64_t n_waves,
+                                                int64_t min_share = IPS_MIN_SHARE) {
   if (w.shift == 0u) return TileShare{wave_index, n_waves, tiles};
   // at least kMinShare sub-tiles per share (the waves behind the last share find nothing to do):
   // the two shared dwords of a share cost four atomics, 2^20-row pages of a narrow column would
   // otherwise be cut into shares of five sub-tiles (Q6 over unaligned pages: 476 -> 4xx us)
-  constexpr int64_t kMinShare = IPS_MIN_SHARE;
   int64_t q = (tiles + n_waves - 1) / n_waves;
-  q = q < kMinShare ? kMinShare : q;
+  q = q < min_share ? min_share : q;
   const int64_t first = wave_index * q;
   return TileShare{first, 1, first + q < tiles ? first + q : tiles};
 }

@@ -622,6 +622,8 @@ __device__ __forceinline__ void fle_pred_body(const uint64_t* __restrict__ enc, 
   int64_t tile = (int64_t)((int)blockIdx.x - args.aux_blocks) * kWavesPerBlock + wave;
   [[maybe_unused]] WindowCarry carry;
   if constexpr (PAGED) {  // this wave's share of the page's sub-tiles
+    // (longer shares for narrow columns -- 32 sub-tiles at w <= 8, 16 at w <= 16 -- left the unaligned
+    // Q6 plan where it was, 446 us: what the contiguous shares cost in streaming order they save in atomics)
     const TileShare sh = tile_share(*win, tiles, tile, stride);
     tile = sh.first;
     stride = sh.step;
@@ -1354,6 +1356,8 @@ __device__ __forceinline__ void fle_pred32_early_body(const uint64_t* __restrict
   int64_t tile = (int64_t)((int)blockIdx.x - args.aux_blocks) * kWavesPerBlock + wave;
   [[maybe_unused]] WindowCarry carry;
   if constexpr (PAGED) {  // this wave's share of the page's sub-tiles
+    // (longer shares for narrow columns -- 32 sub-tiles at w <= 8, 16 at w <= 16 -- left the unaligned
+    // Q6 plan where it was, 446 us: what the contiguous shares cost in streaming order they save in atomics)
     const TileShare sh = tile_share(*win, tiles, tile, stride);
     tile = sh.first;
     stride = sh.step;
