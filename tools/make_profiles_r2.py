@@ -11,10 +11,10 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "prof_r2")
+src = os.path.join(ROOT, "gpurun_out", os.environ.get("IPS_PROF_DIR", "prof_r2"))
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
-tag = "round2"
+tag = os.environ.get("IPS_PROF_TAG", "round2")
 
 
 def one(pattern):
