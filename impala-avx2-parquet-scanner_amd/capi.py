@@ -43,7 +43,7 @@ SYMBOLS = [
     "ips_nullable_workspace_bytes", "ips_fle_pred_nullable", "ips_dict_pred_nullable",
     "ips_select_nullable_workspace_bytes", "ips_dict_select_nullable",
     "ips_dict_translate", "ips_dict_pred", "ips_dict_decode", "ips_dict_scan", "ips_dict_select",
-    "ips_plain_stride", "ips_plain_pred", "ips_plain_scan", "ips_plain_select",
+    "ips_plain_stride", "ips_plain_pred", "ips_plain_pred_nullable", "ips_plain_scan", "ips_plain_select",
     "ips_bitmap_and", "ips_bitmap_or", "ips_bitmap_fill", "ips_bitmap_count", "ips_bitmap_batch_counts",
     "ips_expand_workspace_bytes", "ips_bitmap_expand",
     "ips_eval_program", "ips_set_program_strategy", "ips_synth_splitmix_u32",
@@ -441,6 +441,28 @@ def plain_pred(page, n_rows, type_, op, literals, semantics=SEM_SQL, bitmap=None
                              v.ctypes.data_as(C.c_void_p), len(v), semantics, _ptr(bitmap),
                              _stream(stream)))
     return bitmap[:_words(n_rows)]
+
+
+def plain_pred_nullable(def_levels, def_bw, max_def, n_rows, page, n_data_rows, type_, op, literals, bitmap=None,
+                        workspace=None, stream=None):
+    """ips_plain_pred_nullable: SQL semantics on an OPTIONAL PLAIN page (stored values + levels)."""
+    v = np.ascontiguousarray(np.atleast_1d(literals), dtype=NP_TYPES[type_])
+    if bitmap is None:
+        bitmap = torch.empty(max(_words(n_rows), 2), dtype=torch.int64, device=def_levels.device)
+    if workspace is None:
+        workspace = nullable_workspace(n_rows, def_levels.device)
+    _ck(lib().ips_plain_pred_nullable(_ptr(def_levels), def_bw, max_def, C.c_int64(n_rows), _ptr(page),
+                                      C.c_int64(n_data_rows), type_, op, v.ctypes.data_as(C.c_void_p), len(v),
+                                      _ptr(bitmap), _ptr(workspace), _stream(stream)))
+    return bitmap[:_words(n_rows)]
+
+
+def nullable_plain_column(def_levels, def_bw, max_def, page, type_, n_data_rows):
+    """An OPTIONAL PLAIN column of a program: levels of all rows + the stored (non-NULL) values."""
+    c = Column()
+    c.encoding, c.bit_width, c.type, c.d_data = COL_PLAIN, 0, type_, page.data_ptr()
+    c.max_def_level, c.d_def_levels, c.def_bit_width, c.n_data_rows = max_def, def_levels.data_ptr(), def_bw, n_data_rows
+    return c
 
 
 # ---- bitmap algebra -------------------------------------------------------------------------

@@ -1131,6 +1131,38 @@ ips_status ips_plain_pred(const void* d_page, int64_t n_rows, ips_type type, ips
   return launch_plain_pred(type, d_page, n_rows, eff, literals, n_literals, d_bitmap, S(stream));
 }
 
+// A predicate on an OPTIONAL PLAIN page under SQL semantics.  The reference's PLAIN branch never looks
+// at the definition levels (hdfs-parquet-scanner.cc:346-348, quirk Q3): a column that overflowed the
+// 40000-entry dictionary (dict-encoding.h:157) and is OPTIONAL is compared against other rows' values
+// there.  Here: the comparison over the page's stored (non-NULL) values, then IntersectBitset into the
+// NOT-NULL positions (:326-331) -- three launches (tile counts, predicate, expand).
+ips_status ips_plain_pred_nullable(const void* d_def_levels, int def_bit_width, int max_def_level, int64_t n_rows,
+                                   const void* d_page, int64_t n_data_rows, ips_type type, ips_op op,
+                                   const void* literals, int n_literals, uint64_t* d_bitmap, void* d_workspace,
+                                   ips_stream stream) {
+  ips_status st = check_nullable(d_def_levels, def_bit_width, max_def_level, n_rows, n_data_rows, d_bitmap,
+                                 d_workspace, "ips_plain_pred_nullable");
+  if (st != IPS_OK) return st;
+  IPS_REQUIRE(valid_type(type), "ips_plain_pred_nullable: bad type %d", (int)type);
+  IPS_REQUIRE(op >= IPS_OP_EQ && op <= IPS_OP_IN, "ips_plain_pred_nullable: bad op %d", (int)op);
+  IPS_REQUIRE(literals && n_literals >= 1 && n_literals <= 16 && (op == IPS_OP_IN || n_literals == 1),
+              "ips_plain_pred_nullable: 1..16 literals, one unless IN");
+  IPS_REQUIRE(n_data_rows == 0 || (d_page && aligned16(d_page)), "ips_plain_pred_nullable: page NULL or misaligned");
+  if (n_rows == 0) return IPS_OK;
+  hipStream_t s = S(stream);
+  const NullableWs ws = nullable_workspace(d_workspace, n_rows);
+  int root_kind = 0;
+  const uint64_t* root = nullptr;
+  st = nullable_prepare_root(d_def_levels, def_bit_width, max_def_level, n_rows, ws, &root_kind, &root, s, /*count_tiles=*/true);
+  if (st != IPS_OK) return st;
+  const int64_t n_sub = n_data_rows < n_rows ? n_data_rows : n_rows;
+  if (n_sub > 0) {
+    st = launch_plain_pred(type, d_page, n_sub, op, literals, n_literals, ws.sub, s);
+    if (st != IPS_OK) return st;
+  }
+  return launch_expand(root_kind, root, ws.sub, n_rows, n_sub, ws.tile_counts, d_bitmap, 0, s);
+}
+
 ips_status ips_plain_scan(const void* d_page, int64_t n_rows, ips_type type, ips_op op,
                           const void* literals, int n_literals, ips_op op2, const void* literal2,
                           ips_semantics semantics, uint64_t* d_bitmap, void* d_batch_values,

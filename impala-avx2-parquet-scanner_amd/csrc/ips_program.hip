@@ -640,6 +640,24 @@ ips_status emit_item(const ChainItem& it, int combine, const ips_column* cols, i
   uint8_t lits[16 * 8], lit2[8];
   for (int j = 0; j < it.a->n_consts; ++j) memcpy(lits + j * sz, &it.a->consts[j], (size_t)sz);
   if (it.b) memcpy(lit2, &it.b->consts[0], (size_t)sz);
+  if (c.max_def_level > 0) {
+    // an OPTIONAL PLAIN column (SQL meaning; the reference ignores the levels here, quirk Q3): the
+    // comparison over the stored values into the shared data-row bitmap, then IntersectBitset into the
+    // NOT-NULL positions with the operand's combine mode
+    NullableCol& nc = nctx.col[it.a->column];
+    const int64_t n_sub = c.n_data_rows < n_rows ? c.n_data_rows : n_rows;
+    if (!nc.counted) {
+      nc.counted = true;
+      ips_status st = launch_rank_tile_counts(nc.root_kind, nc.root, n_rows, nc.tile_counts, s);
+      if (st != IPS_OK) return st;
+    }
+    if (n_sub > 0) {
+      ips_status st = launch_plain_pred(c.type, c.d_data, n_sub, it.a->op, lits, it.a->n_consts, nctx.sub, s, 0,
+                                        it.b ? it.join : 0, it.b ? it.b->op : 0, it.b ? lit2 : nullptr);
+      if (st != IPS_OK) return st;
+    }
+    return launch_expand(nc.root_kind, nc.root, nctx.sub, n_rows, n_sub, nc.tile_counts, d_bitmap, combine, s);
+  }
   return launch_plain_pred(c.type, c.d_data, n_rows, it.a->op, lits, it.a->n_consts, d_bitmap, s,
                            combine, it.b ? it.join : 0, it.b ? it.b->op : 0, it.b ? lit2 : nullptr);
 }
@@ -837,7 +855,6 @@ extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const
                   "ips_eval_program: column %d: data NULL or misaligned", nd.column);
       IPS_REQUIRE(c.max_def_level >= 0, "ips_eval_program: column %d: max_def_level < 0", nd.column);
       if (c.max_def_level > 0) {
-        IPS_REQUIRE(c.encoding == IPS_COL_FLE, "ips_eval_program: column %d: OPTIONAL columns must be FLE", nd.column);
         IPS_REQUIRE(c.def_bit_width >= 1 && c.def_bit_width <= 32 &&
                     (c.def_bit_width == 32 || (uint64_t)c.max_def_level < (1ull << c.def_bit_width)),
                     "ips_eval_program: column %d: max_def_level does not fit the level width", nd.column);

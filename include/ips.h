@@ -335,6 +335,17 @@ ips_status ips_plain_pred(const void* d_page, int64_t n_rows, ips_type type, ips
                           const void* literals, int n_literals, ips_semantics semantics,
                           uint64_t* d_bitmap, ips_stream stream);
 
+/* ips_plain_pred (SQL semantics) on an OPTIONAL PLAIN page: d_page holds the page's n_data_rows stored
+ * (non-NULL) values, d_def_levels the FLE levels of all n_rows rows; bit r = row r is not NULL and
+ * its value passes.  The reference's PLAIN branch ignores the levels altogether (hdfs-parquet-
+ * scanner.cc:346-348: an OPTIONAL column that fell back from dictionary to PLAIN pages, dict-encoding.h:
+ * 157, is compared against other rows' values there), so there is no REFERENCE-semantics form of this.
+ * Workspace: ips_nullable_workspace_bytes(n_rows). */
+ips_status ips_plain_pred_nullable(const void* d_def_levels, int def_bit_width, int max_def_level,
+                                   int64_t n_rows, const void* d_page, int64_t n_data_rows,
+                                   ips_type type, ips_op op, const void* literals, int n_literals,
+                                   uint64_t* d_bitmap, void* d_workspace, ips_stream stream);
+
 /* Fused scan of a PLAIN page: bitmap of (x op literal) [AND (x op2 literal2) when literal2 != NULL:
  * a BETWEEN as And(Ge, Le), simple-predicates.h:145-153] plus the selected rows' slots, one pass over
  * the page -- EvalSimplePredicates + ReadValue(skip) on the same PLAIN column
@@ -394,8 +405,9 @@ typedef struct {
   int32_t encoding;         /* ips_col_encoding */
   int32_t bit_width;        /* FLE: 1..32 */
   int32_t type;             /* PLAIN: ips_type */
-  int32_t max_def_level;    /* 0 = REQUIRED column; > 0 = OPTIONAL (FLE encoding only: the reference's
-                               PLAIN branch ignores definition levels, hdfs-parquet-scanner.cc:346-348) */
+  int32_t max_def_level;    /* 0 = REQUIRED column; > 0 = OPTIONAL (FLE: the reader's nullable branch,
+                               hdfs-parquet-scanner.cc:338-345; PLAIN: SQL meaning -- NULL rows fail, the stored
+                               values are compared -- where the reference ignores the levels, :346-348) */
   const void* d_data;       /* FLE blocks or PLAIN page (OPTIONAL: of the non-NULL rows only) */
   const void* d_def_levels; /* OPTIONAL: FLE blocks of the n_rows definition levels */
   int32_t def_bit_width;    /* OPTIONAL: Log2(max_def_level + 1) */
