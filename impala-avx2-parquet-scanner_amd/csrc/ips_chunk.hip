@@ -60,6 +60,52 @@ ips_status launch_fle_scan_chunk(int w, int mode, int gather, const ChunkPage* d
 #undef IPS_A
 }
 
+// Edge mode's second launch: thread t of page blockIdx.y owns the bitmap dword at the START of the
+// page's sub-tile t (t = tiles: the dword behind the last one): the high part of sub-tile t - 1 and the
+// low part of sub-tile t, which the paged kernel left in the edge slots.  Inside a page such a dword is
+// complete (plain store / read-modify-write); at the page's two ends it is shared with the
+// neighbouring pages and merged atomically -- two atomics per page.
+__global__ __launch_bounds__(256) void window_fixup_kernel(const ChunkPage* __restrict__ pages, int64_t chunk_rows,
+                                                           uint32_t* __restrict__ bitmap32,
+                                                           const uint32_t* __restrict__ edges, int combine) {
+  const ChunkPage pg = pages[blockIdx.y];
+  const BitmapWindow w = bitmap_window(bitmap32, pg, chunk_rows);
+  if (w.shift == 0u) return;
+  const int64_t tiles = (pg.n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > tiles) return;
+  const uint32_t s = w.shift, r = 32u - s;
+  const uint32_t* e = edges + 4 * (size_t)pg.batch0;
+  auto rows_mask = [&](int64_t dword) -> uint32_t {  // rows of the page inside page-relative dword 'dword'
+    const int64_t valid = pg.n_rows - dword * 32;
+    return valid >= 32 ? ~0u : valid <= 0 ? 0u : ((1u << valid) - 1u);
+  };
+  uint32_t val = 0u, mask = 0u;
+  if (t < tiles) {
+    val |= e[4 * t];
+    mask |= rows_mask(64 * t) << s;
+  }
+  if (t > 0) {
+    val |= e[4 * (t - 1) + 1];
+    mask |= rows_mask(64 * t - 1) >> r;
+  }
+  const int64_t d = 64 * t;
+  const bool tail = w.own_tail && d == w.tail_dword && mask != 0u;
+  if (tail) mask |= w.tail_mask;
+  window_put(w.base + d, val & mask, mask, combine, 0u);
+  if (tail && w.tail_extra && combine != 2) IPS_BITMAP_STORE(w.base + d + 1, 0u);
+}
+
+ips_status launch_window_fixup(const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
+                               uint32_t* bitmap32, const uint32_t* edges, int combine, hipStream_t s) {
+  if (n_pages <= 0 || edges == nullptr) return IPS_OK;
+  const int64_t tiles = (max_rows + kRowsPerTile - 1) / kRowsPerTile;
+  hipLaunchKernelGGL(window_fixup_kernel, dim3((unsigned)((tiles + 1 + 255) / 256), (unsigned)n_pages), dim3(256), 0, s,
+                     d_pages, chunk_rows, bitmap32, edges, combine);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
 // The predicate of one operand on a run of pages of width bw.  A constant that does not fit the
 // run's width (a code of a later, larger dictionary state) makes that comparison
 // constant on the run: always true becomes GE 0, always false LT 0 -- evaluated by the same kernels,
@@ -123,6 +169,7 @@ ips_status ips_chunk_open(const ips_chunk_page* h_pages, int n_pages, int encodi
   c->n_rows = 0;
   c->n_batches = 0;
   c->d_pages = nullptr;
+  c->d_edges = nullptr;
   c->rank_entries = 0;
   auto fail = [&](const char* msg, int i) {
     set_error("ips_chunk_open: page %d: %s", i, msg);
@@ -171,7 +218,16 @@ ips_status ips_chunk_open(const ips_chunk_page* h_pages, int n_pages, int encodi
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->d_pages), bytes);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipMalloc(page table)"); }
     e = hipMemcpy(c->d_pages, c->pages.data(), bytes, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(c->d_pages); delete c; return hip_fail(e, "hipMemcpy(page table)"); }
+    bool shifted = false;
+    for (const ChunkPage& pg : c->pages) shifted = shifted || (pg.row0 & 31) != 0;
+    if (e == hipSuccess && shifted && max_def_level == 0)  // (OPTIONAL chunks go through the leaf kernel: no edge mode)
+      e = hipMalloc(reinterpret_cast<void**>(&c->d_edges), (size_t)c->n_batches * 16);
+    if (e != hipSuccess) {
+      (void)hipFree(c->d_pages);
+      if (c->d_edges) (void)hipFree(c->d_edges);
+      delete c;
+      return hip_fail(e, "ips_chunk_open(page table)");
+    }
   }
   *chunk = c;
   return IPS_OK;
@@ -180,6 +236,7 @@ ips_status ips_chunk_open(const ips_chunk_page* h_pages, int n_pages, int encodi
 ips_status ips_chunk_close(ips_chunk* chunk) {
   if (!chunk) return IPS_OK;
   if (chunk->d_pages) (void)hipFree(chunk->d_pages);
+  if (chunk->d_edges) (void)hipFree(chunk->d_edges);
   delete chunk;
   return IPS_OK;
 }
@@ -218,11 +275,18 @@ ips_status scan_runs(const ips_chunk* chunk, int mode_hint, int op, const uint64
       set_error("dictionary codes wider than 16 bits (page run of width %d)", run.bit_width);
       return IPS_ERR_INVALID_ARG;
     }
+    const bool emits = mode_hint != kScanGivenBitmap;
+    args.edges = emits ? chunk->d_edges : nullptr;
     ips_status st = launch_fle_scan_chunk(run.bit_width, mode, gather, chunk->d_pages + run.first, run.count,
                                           run.max_rows, chunk->n_rows, args, reinterpret_cast<uint32_t*>(d_bitmap),
                                           reinterpret_cast<const uint32_t*>(d_given), d_batch_values, d_batch_counts,
                                           d_dict, dict_entries, nullptr, s);
     if (st != IPS_OK) return st;
+    if (emits && chunk->d_edges) {
+      st = launch_window_fixup(chunk->d_pages + run.first, run.count, run.max_rows, chunk->n_rows,
+                               reinterpret_cast<uint32_t*>(d_bitmap), chunk->d_edges, 0, s);
+      if (st != IPS_OK) return st;
+    }
   }
   return IPS_OK;
 }
@@ -298,7 +362,7 @@ ips_status ips_chunk_plain_scan(const ips_chunk* chunk, ips_op op, const void* l
   const ips_chunk::Run& run = chunk->runs[0];  // PLAIN pages form one run
   return launch_plain_scan_pages(chunk->type, chunk->d_pages, (int)chunk->pages.size(), run.max_rows, chunk->n_rows,
                                  flip(op), literals, n_literals, literal2 ? 1 : 0, literal2 ? flip(op2) : 0, literal2,
-                                 d_bitmap, d_batch_values, d_batch_counts, S(stream));
+                                 d_bitmap, d_batch_values, d_batch_counts, S(stream), chunk->d_edges);
 }
 
 }  // extern "C"

@@ -47,6 +47,7 @@ struct BitmapWindow {
   int64_t tail_dword;    // last page: page-relative index of the dword that holds the chunk's last row
   uint32_t tail_mask;    //            its bits behind that row
   uint32_t tail_extra;   //            1: the bitmap's last word has one more dword behind it
+  uint32_t* edges;       // the page's edge slots (4 dwords per sub-tile: [lo, hi, -, -]) or NULL, see window_emit
   uint32_t coherent;     // 1: the dwords are stored device-coherently (written through to memory: a sharded
                          //    step hands pages to the exchange while the launch is still running, page_done)
 };
@@ -57,8 +58,9 @@ __device__ __forceinline__ void window_store(uint32_t* p, uint32_t v, uint32_t c
 }
 
 __device__ __forceinline__ BitmapWindow bitmap_window(uint32_t* bitmap32, const ChunkPage& pg, int64_t chunk_rows,
-                                                      const void* done = nullptr) {
+                                                      const void* done = nullptr, uint32_t* edges = nullptr) {
   BitmapWindow w;
+  w.edges = edges ? edges + 4 * (size_t)pg.batch0 : nullptr;
   // (device-coherent dword stores were tried for pages that are handed on while the launch is still
   // running: 439 us instead of 224 for the w = 32 scan -- the bitmap stays nt stores, see page_done)
   w.coherent = 0u;
@@ -133,7 +135,22 @@ __device__ __forceinline__ void window_emit(const BitmapWindow& w, WindowCarry& 
   const uint32_t vm = lane > last_lane ? 0u : valid >= 32 ? ~0u : valid <= 0 ? 0u : ((1u << valid) - 1u);
   bm &= vm;
   uint32_t val = bm, mask = vm;
-  if (w.shift != 0u) {  // wave-uniform
+  if (w.shift != 0u && w.edges != nullptr && last_lane == kWave - 1) {  // wave-uniform
+    // Edge mode (sub-tile runs of 64 dwords): the run's two end dwords -- the low part of lane 0, the
+    // high part of lane 63 -- go to the sub-tile's edge slot with plain stores and window_fixup_kernel
+    // merges neighbouring sub-tiles' parts afterwards: no atomics in this kernel, any sub-tile order.
+    const uint32_t s = w.shift, r = 32u - s;
+    const uint32_t up_bm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bm, 0x138, 0xF, 0xF, true);  // wave_shr:1
+    const uint32_t up_vm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vm, 0x138, 0xF, 0xF, true);
+    uint32_t* slot = w.edges + 4 * ((d - lane) >> 6);
+    if (lane == 0) {
+      slot[0] = bm << s;
+      return;
+    }
+    if (lane == kWave - 1) slot[1] = bm >> r;
+    val = (bm << s) | (up_bm >> r);
+    mask = (vm << s) | (up_vm >> r);
+  } else if (w.shift != 0u) {  // wave-uniform
     const int64_t d0 = d - lane;
     if (cy.next != d0) window_flush(w, cy, combine);  // (not the run that follows the carried one)
     const uint32_t s = w.shift, r = 32u - s;
@@ -198,7 +215,7 @@ __device__ __forceinline__ void window_emit_quad(const BitmapWindow& w, WindowCa
 struct TileShare { int64_t first, step, end; };
 __device__ __forceinline__ TileShare tile_share(const BitmapWindow& w, int64_t tiles, int64_t wave_index, int64_t n_waves,
                                                 int64_t min_share = IPS_MIN_SHARE) {
-  if (w.shift == 0u) return TileShare{wave_index, n_waves, tiles};
+  if (w.shift == 0u || w.edges != nullptr) return TileShare{wave_index, n_waves, tiles};
   // at least kMinShare sub-tiles per share (the waves behind the last share find nothing to do):
   // the two shared dwords of a share cost four atomics, 2^20-row pages of a narrow column would
   // otherwise be cut into shares of five sub-tiles (Q6 over unaligned pages: 476 -> 4xx us)

@@ -20,6 +20,10 @@ struct ips_chunk {
   std::vector<Run> runs;
   ips::ChunkPage* d_pages;            // the same on the device
   uint32_t rank_entries;              // OPTIONAL: entries (uint32) of all pages' tile-count tables
+  // pages that start inside a bitmap dword: 4 dwords per batch slot for the end dwords of the sub-tiles
+  // (edge mode of the paged kernels, ips_chunk_device.h); NULL when every page starts on a multiple of
+  // 32 rows.  One evaluation at a time may use it (handles are thread-compatible).
+  uint32_t* d_edges;
 };
 
 namespace ips {
@@ -38,12 +42,17 @@ ips_status launch_fle_scan_chunk(int w, int mode, int gather, const ChunkPage* d
                                  void* batch_values, uint32_t* batch_counts, const void* dict, uint32_t dict_entries,
                                  int32_t* bad_index, hipStream_t s);
 // PLAIN pages (ips_plain.hip)
+// (edges: the chunk's edge slots or NULL; 4-byte slots use them and run the fix-up themselves)
 ips_status launch_plain_pred_pages(int type, const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
                                    int op, const void* literals, int n_literals, uint64_t* bitmap, hipStream_t s,
-                                   int combine, int join, int op2, const void* literal2);
+                                   int combine, int join, int op2, const void* literal2, uint32_t* edges);
 ips_status launch_plain_scan_pages(int type, const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
                                    int op, const void* literals, int n_literals, int join, int op2, const void* literal2,
-                                   uint64_t* bitmap, void* batch_values, uint32_t* batch_counts, hipStream_t s);
+                                   uint64_t* bitmap, void* batch_values, uint32_t* batch_counts, hipStream_t s,
+                                   uint32_t* edges);
+// edge mode's second launch over the same pages (ips_chunk.hip)
+ips_status launch_window_fixup(const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
+                               uint32_t* bitmap32, const uint32_t* edges, int combine, hipStream_t s);
 // tile counts of every page's definition levels (ips_rank.hip): page p's table at counts + page.rank0
 ips_status launch_rank_counts_pages(const ChunkPage* d_pages, int n_pages, int64_t max_rows, uint32_t* counts,
                                     hipStream_t s);

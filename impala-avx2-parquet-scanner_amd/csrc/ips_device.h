@@ -59,6 +59,9 @@ struct PredArgs {
   const uint32_t* in_list;
   int32_t in_list_n;
   int32_t reserved2;
+  // paged launches over a chunk with pages that start inside a bitmap dword: the two end dwords of
+  // every sub-tile go to the chunk's edge slots and a fix-up launch merges them (ips_chunk_device.h)
+  uint32_t* edges;
   uint32_t consts[256];
 };
 

@@ -582,7 +582,7 @@ __global__ __launch_bounds__(kThreads, (ScanLds<W, MODE>::kMinWaves)) void fle_s
     uint32_t dict_entries, int32_t* __restrict__ bad_index) {
   PageCtx pc;
   pc.page = pages[blockIdx.y];
-  pc.win = bitmap_window(bitmap32, pc.page, chunk_rows, args.done);
+  pc.win = bitmap_window(bitmap32, pc.page, chunk_rows, args.done, MODE == kScanGivenBitmap ? nullptr : args.edges);
   pc.total_dwords = bitmap_dwords(chunk_rows);
   const TileShare sh = tile_share(pc.win, (pc.page.n_data + kRowsPerTile - 1) / kRowsPerTile,
                                   (int64_t)blockIdx.x * kWavesPerBlock + wave_id(), (int64_t)gridDim.x * kWavesPerBlock);
@@ -691,7 +691,7 @@ template <int W, int KIND>
 __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred_pages_kernel(
     const ChunkPage* __restrict__ pages, int64_t chunk_rows, PredArgs args, uint32_t* __restrict__ bitmap32) {
   const ChunkPage pg = pages[blockIdx.y];
-  const BitmapWindow win = bitmap_window(bitmap32, pg, chunk_rows, args.done);
+  const BitmapWindow win = bitmap_window(bitmap32, pg, chunk_rows, args.done, args.edges);
   fle_pred_body<W, KIND, true>(pg.data, pg.n_data, args, nullptr, &win);
   page_done(args.done, args.done_page0, args.done_epoch);
 }
@@ -1425,7 +1425,7 @@ template <int W, bool PAIR>
 __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_pred32_early_pages_kernel(
     const ChunkPage* __restrict__ pages, int64_t chunk_rows, PredArgs args, uint32_t* __restrict__ bitmap32) {
   const ChunkPage pg = pages[blockIdx.y];
-  const BitmapWindow win = bitmap_window(bitmap32, pg, chunk_rows, args.done);
+  const BitmapWindow win = bitmap_window(bitmap32, pg, chunk_rows, args.done, args.edges);
   fle_pred32_early_body<W, PAIR, true>(pg.data, pg.n_data, args, nullptr, &win);
   page_done(args.done, args.done_page0, args.done_epoch);
 }

@@ -34,6 +34,7 @@ struct PlainLit {
   int32_t join;     // 0 none; 1 / 2: AND / OR with (x op2 v2) in the same pass
   int32_t op2;
   T v2;
+  uint32_t* edges;  // paged launches, 4-byte slots: the chunk's edge slots (edge mode) or NULL
 };
 
 // T = compared type, S = slot type (uint32_t for 4-byte slots, uint64_t for 8-byte slots)
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(kThreads, 4) void plain_tile_pages_kernel(const Chu
                                                                     S* __restrict__ batch_values,
                                                                     uint32_t* __restrict__ batch_counts) {
   const ChunkPage pg = pages[blockIdx.y];
-  const BitmapWindow win = bitmap_window(bitmap32, pg, chunk_rows);
+  const BitmapWindow win = bitmap_window(bitmap32, pg, chunk_rows, nullptr, sizeof(S) == 4 ? lit.edges : nullptr);
   plain_tile_body<T, S, SCAN, true>(reinterpret_cast<const S*>(pg.data), pg.n_rows, op, lit, nullptr,
                                     SCAN ? batch_values + (int64_t)pg.batch0 * kRowsPerTile : nullptr,
                                     SCAN ? batch_counts + pg.batch0 : nullptr, &win);
@@ -350,6 +351,7 @@ static ips_status launch_plain_tiles(const void* page, int64_t n_rows, int op, c
   lit.join = join;
   lit.op2 = op2;
   lit.v2 = literal2 ? *reinterpret_cast<const T*>(literal2) : T();
+  lit.edges = nullptr;
   for (int i = 0; i < 16; ++i) lit.v[i] = i < n_literals ? reinterpret_cast<const T*>(literals)[i] : T();
   auto kern = plain_tile_kernel<T, S, SCAN>;
   const int64_t n_batches = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
@@ -365,8 +367,9 @@ template <typename T, typename S, bool SCAN>
 static ips_status launch_plain_tiles_pages(const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
                                            int op, const void* literals, int n_literals, int combine, int join,
                                            int op2, const void* literal2, uint64_t* bitmap, void* batch_values,
-                                           uint32_t* batch_counts, hipStream_t s) {
+                                           uint32_t* batch_counts, hipStream_t s, uint32_t* edges) {
   PlainLit<T> lit;
+  lit.edges = sizeof(S) == 4 ? edges : nullptr;
   lit.n = n_literals;
   lit.combine = combine;
   lit.join = join;
@@ -380,6 +383,9 @@ static ips_status launch_plain_tiles_pages(const ChunkPage* d_pages, int n_pages
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)n_pages), dim3(kThreads), 0, s, d_pages, chunk_rows, op, lit,
                      reinterpret_cast<uint32_t*>(bitmap), reinterpret_cast<S*>(batch_values), batch_counts);
   IPS_HIP_TRY(hipGetLastError());
+  if (lit.edges)  // edge mode: the sub-tiles' end dwords are merged by a second launch
+    return launch_window_fixup(d_pages, n_pages, max_rows, chunk_rows, reinterpret_cast<uint32_t*>(bitmap), lit.edges,
+                               combine, s);
   return IPS_OK;
 }
 
@@ -420,10 +426,10 @@ ips_status launch_plain_pred(int type, const void* page, int64_t n_rows, int op,
 
 ips_status launch_plain_pred_pages(int type, const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
                                    int op, const void* literals, int n_literals, uint64_t* bitmap, hipStream_t s,
-                                   int combine, int join, int op2, const void* literal2) {
+                                   int combine, int join, int op2, const void* literal2, uint32_t* edges) {
 #define IPS_PL(T, S)                                                                                               \
   return launch_plain_tiles_pages<T, S, false>(d_pages, n_pages, max_rows, chunk_rows, op, literals, n_literals,   \
-                                               combine, join, op2, literal2, bitmap, nullptr, nullptr, s)
+                                               combine, join, op2, literal2, bitmap, nullptr, nullptr, s, edges)
   IPS_PLAIN_TYPES(IPS_PL)
 #undef IPS_PL
   set_error("plain_pred_pages: bad type %d", type);
@@ -432,10 +438,11 @@ ips_status launch_plain_pred_pages(int type, const ChunkPage* d_pages, int n_pag
 
 ips_status launch_plain_scan_pages(int type, const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
                                    int op, const void* literals, int n_literals, int join, int op2, const void* literal2,
-                                   uint64_t* bitmap, void* batch_values, uint32_t* batch_counts, hipStream_t s) {
+                                   uint64_t* bitmap, void* batch_values, uint32_t* batch_counts, hipStream_t s,
+                                   uint32_t* edges) {
 #define IPS_PS(T, S)                                                                                             \
   return launch_plain_tiles_pages<T, S, true>(d_pages, n_pages, max_rows, chunk_rows, op, literals, n_literals, 0, \
-                                              join, op2, literal2, bitmap, batch_values, batch_counts, s)
+                                              join, op2, literal2, bitmap, batch_values, batch_counts, s, edges)
   IPS_PLAIN_TYPES(IPS_PS)
 #undef IPS_PS
   set_error("plain_scan_pages: bad type %d", type);

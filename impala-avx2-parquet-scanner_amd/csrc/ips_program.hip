@@ -1035,7 +1035,10 @@ ips_status emit_item_chunk(const ChainItem& it, int combine, const ips_chunk* co
         args.aux_counts = ctx.rank[col];
         st = launch_fle_leaf_pages(run.bit_width, c->d_pages + run.first, run.count, run.max_rows, n_rows, args, bm32, s);
       } else {
+        args.edges = done ? nullptr : c->d_edges;  // (a signalling launch merges its shared dwords itself)
         st = launch_fle_pred_pages(run.bit_width, c->d_pages + run.first, run.count, run.max_rows, n_rows, args, bm32, s);
+        if (st == IPS_OK && args.edges)
+          st = launch_window_fixup(c->d_pages + run.first, run.count, run.max_rows, n_rows, bm32, c->d_edges, combine, s);
       }
       if (st != IPS_OK) return st;
     }
@@ -1048,7 +1051,7 @@ ips_status emit_item_chunk(const ChainItem& it, int combine, const ips_chunk* co
   if (it.b) memcpy(lit2, &it.b->consts[0], (size_t)sz);
   return launch_plain_pred_pages(c->type, c->d_pages, (int)c->pages.size(), c->runs[0].max_rows, n_rows, it.a->op,
                                  lits, it.a->n_consts, d_bitmap, s, combine, it.b ? it.join : 0, it.b ? it.b->op : 0,
-                                 it.b ? lit2 : nullptr);
+                                 it.b ? lit2 : nullptr, c->d_edges);
 }
 
 ips_status check_chunk_program(const ips_node* nodes, int n_nodes, const ips_chunk* const* chunks, int n_chunks,
