@@ -98,6 +98,7 @@
 // IPS_SELECT_NULLABLE_STEPS=1  ips_dict_select_nullable composed from ten launches
 // IPS_NO_SHARED_DICT=1         large dictionaries gathered from L2 instead of the shared LDS copy
 // IPS_NO_COUNT_CARRY=1         tile counts of an OPTIONAL column as a launch of their own
+// IPS_PAGED_GRID_DIV=<k>       paged launches with 1/k of the usual workgroups (measured: 2 and 4 are slower)
 // IPS_SHARD_NO_EXCHANGE=1      ips_fle_scan_allgather launches its signalling scan and no waiter / all-gather
 namespace ips {
 inline const char* dev_env(const char* name) {
