@@ -706,6 +706,7 @@ class Chunk:
         self.n_rows = int(L.ips_chunk_num_rows(self.h))
         self.n_batches = int(L.ips_chunk_num_batches(self.h))
         self.type = type_
+        self.encoding = encoding
         self.device = next((pg[0].device for pg in pages if pg[0] is not None), torch.device("cuda"))
 
     def close(self):
@@ -753,7 +754,11 @@ class Chunk:
         return self._ret(outs)
 
     def select(self, bitmap, dict_=None, outputs=None, stream=None):
-        outs = outputs or self.alloc_outputs(TORCH_SLOT[dict_.type] if dict_ else torch.int32)
+        if self.encoding == COL_PLAIN:
+            dt = torch.int32 if int(lib().ips_plain_stride(self.type)) == 4 else torch.int64
+        else:
+            dt = TORCH_SLOT[dict_.type] if dict_ else torch.int32
+        outs = outputs or self.alloc_outputs(dt)
         _ck(lib().ips_chunk_select(self.h, dict_.h if dict_ else None, _ptr(bitmap), _ptr(outs[1]), _ptr(outs[2]),
                                    _stream(stream)))
         return outs[1], outs[2][:self.n_batches]

@@ -559,7 +559,7 @@ ips_status ips_assemble_tuples(const ips_tuple_column* cols, int n_cols,
                   cols[i].null_bit_mask > 0 && cols[i].null_bit_mask < 256,
                   "ips_assemble_tuples: column %d: bad NULL indicator", i);
     } else {
-      IPS_REQUIRE(n_rows == 0 || cols[i].d_batch_values, "ips_assemble_tuples: column %d: NULL values", i);
+      IPS_REQUIRE(n_rows == 0 || cols[i].d_batch_values || cols[i].d_dense_values, "ips_assemble_tuples: column %d: NULL values", i);
     }
   }
   return launch_assemble_tuples(cols, n_cols, d_batch_counts, n_batches_of(n_rows), tuple_size,

@@ -332,7 +332,14 @@ ips_status ips_chunk_select(const ips_chunk* chunk, const ips_dict* dict, const 
                             void* d_batch_values, uint32_t* d_batch_counts, ips_stream stream) {
   ips_status st = check_scan_outputs(chunk, d_bitmap, d_batch_values, d_batch_counts, "ips_chunk_select");
   if (st != IPS_OK) return st;
-  IPS_REQUIRE(chunk->encoding == IPS_COL_FLE && chunk->max_def_level == 0, "ips_chunk_select: a REQUIRED FLE / dictionary chunk");
+  IPS_REQUIRE(chunk->max_def_level == 0, "ips_chunk_select: a REQUIRED chunk (OPTIONAL pages: ips_dict_select_nullable page by page)");
+  if (chunk->encoding == IPS_COL_PLAIN) {  // ReadValue(skip) -> ParquetPlainEncoder::Decode(.., skip_rows), parquet-common.h:186-190
+    IPS_REQUIRE(dict == nullptr, "ips_chunk_select: a PLAIN chunk has no dictionary");
+    if (chunk->pages.empty()) return IPS_OK;
+    return launch_plain_select_pages(ips_plain_stride((ips_type)chunk->type), chunk->d_pages, (int)chunk->pages.size(),
+                                     chunk->runs[0].max_rows, chunk->n_rows, d_bitmap, d_batch_values, d_batch_counts,
+                                     S(stream));
+  }
   return scan_runs(chunk, kScanGivenBitmap, 0, nullptr, 0, dict ? dict->slot : 0, dict ? dict->d_entries : nullptr,
                    dict ? (uint32_t)dict->n : 0u, nullptr, d_bitmap, d_batch_values, d_batch_counts, S(stream));
 }

@@ -225,25 +225,31 @@ __device__ __forceinline__ TileShare tile_share(const BitmapWindow& w, int64_t t
   return TileShare{first, 1, first + q < tiles ? first + q : tiles};
 }
 
-// The other direction: this lane's dword of a selection over the chunk's rows (bit j <-> row
-// 32 * lane + j of sub-tile 'tile' of the page; rows beyond the page cleared).  'words32' dwords
-// exist in the bitmap.
-__device__ __forceinline__ uint32_t window_fetch(const uint32_t* __restrict__ bitmap32, int64_t total_dwords,
-                                                 const ChunkPage& pg, int64_t tile, int lane) {
-  const int64_t d = tile * 64 + lane;
+// The other direction: the wave reads a run of consecutive page-relative dwords of a selection over
+// the chunk's rows, lane l the dword d = d0 + l (bit j <-> row 32 d + j of the page; rows beyond the
+// page cleared).  Every lane calls it; lanes with active = false get 0 (they still fetch: the lane
+// before them takes its high part from them).  total_dwords: dwords of the bitmap.
+__device__ __forceinline__ uint32_t window_fetch_at(const uint32_t* __restrict__ bitmap32, int64_t total_dwords,
+                                                    const ChunkPage& pg, int64_t d, bool active) {
+  const int lane = (int)(threadIdx.x & (kWave - 1));
   const int64_t g = (pg.row0 >> 5) + d;
   const uint32_t s = (uint32_t)(pg.row0 & 31);
   const int64_t valid = pg.n_rows - d * 32;
   if (__builtin_amdgcn_ballot_w64(valid > 0) == 0ull) return 0u;  // wave-uniform: nothing of the page here
   // (a dword right behind the page's last row of this lane may still hold rows of the lane before it)
-  uint32_t lo = (valid > -32 && g < total_dwords) ? bitmap32[g] : 0u;
+  const uint32_t lo = (valid > -32 && g < total_dwords) ? bitmap32[g] : 0u;
   uint32_t x = lo;
   if (s != 0u) {  // wave-uniform
     uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x130, 0xF, 0xF, true);  // wave_shl:1: lane i <- lane i + 1
     if (lane == kWave - 1) hi = (valid > 0 && g + 1 < total_dwords) ? bitmap32[g + 1] : 0u;  // (the last lane has no neighbour)
     x = (lo >> s) | (hi << (32u - s));
   }
+  if (!active) return 0u;
   return valid >= 32 ? x : valid <= 0 ? 0u : (x & ((1u << valid) - 1u));
+}
+__device__ __forceinline__ uint32_t window_fetch(const uint32_t* __restrict__ bitmap32, int64_t total_dwords,
+                                                 const ChunkPage& pg, int64_t tile, int lane) {
+  return window_fetch_at(bitmap32, total_dwords, pg, tile * 64 + lane, true);
 }
 
 // End of a wave's work on page blockIdx.y of a launch whose pages are being waited for one by one

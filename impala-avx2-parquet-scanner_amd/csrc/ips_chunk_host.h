@@ -50,6 +50,9 @@ ips_status launch_plain_scan_pages(int type, const ChunkPage* d_pages, int n_pag
                                    int op, const void* literals, int n_literals, int join, int op2, const void* literal2,
                                    uint64_t* bitmap, void* batch_values, uint32_t* batch_counts, hipStream_t s,
                                    uint32_t* edges);
+ips_status launch_plain_select_pages(int stride_bytes, const ChunkPage* d_pages, int n_pages, int64_t max_rows,
+                                     int64_t chunk_rows, const uint64_t* bitmap, void* batch_values,
+                                     uint32_t* batch_counts, hipStream_t s);
 // edge mode's second launch over the same pages (ips_chunk.hip)
 ips_status launch_window_fixup(const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
                                uint32_t* bitmap32, const uint32_t* edges, int combine, hipStream_t s);

@@ -388,6 +388,7 @@ struct TupleCols {
   int32_t offset[IPS_TUPLE_MAX_COLS];
   int32_t null_byte[IPS_TUPLE_MAX_COLS];
   int32_t null_mask[IPS_TUPLE_MAX_COLS];
+  int32_t dense[IPS_TUPLE_MAX_COLS];            // REQUIRED column given as ONE dense array: tuple i takes value i
   int32_t n_cols;
   int32_t tuple_size;
   const uint8_t* d_template;                    // wide tuples: device copy of the template tuple
@@ -517,7 +518,9 @@ __global__ __launch_bounds__(kThreads) void assemble_tuples_kernel(
         const uint64_t gi = first + i;  // index of this tuple among all selected rows
         for (int col = 0; col < tc.n_cols; ++col) {
           uint64_t src = (uint64_t)batch * kRowsPerTile + i;
-          if (tc.flags[col]) {  // OPTIONAL column: NULL bit, or the rank-th dense value
+          if (tc.dense[col]) {  // a dense REQUIRED column (materialised over page lists): value gi
+            src = gi;
+          } else if (tc.flags[col]) {  // OPTIONAL column: NULL bit, or the rank-th dense value
             const uint64_t fw = tc.flags[col][gi >> 6];
             if (!((fw >> (gi & 63)) & 1ull)) {
               *at(tc.null_byte[col]) |= (uint8_t)tc.null_mask[col];
@@ -615,6 +618,9 @@ ips_status launch_assemble_tuples(const ips_tuple_column* cols, int n_cols, cons
       hipLaunchKernelGGL(word_prefix_kernel, dim3((unsigned)fb), dim3(kScanThreads), 0, s,
                          tc.flags[i], n_rows_cap, f_totals, f_prefix);
       tc.prefix[i] = f_prefix;
+    } else if (cols[i].d_dense_values) {
+      tc.values[i] = cols[i].d_dense_values;
+      tc.dense[i] = 1;
     } else {
       tc.values[i] = cols[i].d_batch_values;
     }
@@ -637,7 +643,7 @@ ips_status launch_assemble_tuples(const ips_tuple_column* cols, int n_cols, cons
   const int grid = per_batch_grid(n_batches);
   bool fast = image;
   for (int i = 0; i < n_cols; ++i)
-    fast = fast && !cols[i].d_nonnull_flags && cols[i].value_width == 4 && (cols[i].tuple_offset & 3) == 0;
+    fast = fast && !cols[i].d_nonnull_flags && !cols[i].d_dense_values && cols[i].value_width == 4 && (cols[i].tuple_offset & 3) == 0;
   const size_t wave_image = (size_t)kWave * tuple_size;
   const size_t lds = image ? (size_t)kWavesPerBlock * (wave_image + (tuple_size >= kTuplePadMin ? ((wave_image >> 8) << 2) : 0)) : 0;
   uint8_t* out = reinterpret_cast<uint8_t*>(tuples);

@@ -239,11 +239,14 @@ __device__ __forceinline__ int64_t plain_next_tile(int64_t tile, int64_t waves) 
 // rows' slots per 2048-row batch + batch counts.
 // PAGED: page / n_rows are one page of a column chunk, the bitmap is the chunk's (the lane dwords go
 // through the page's window, ips_chunk_device.h), the batch outputs start at the page's first slot.
-template <typename T, typename S, bool SCAN, bool PAGED>
+// GIVEN (paged scans only): no comparison -- the lane's rows are selected by a bitmap over the chunk's
+// rows (ReadValue(skip) against a selection, parquet-common.h:186-190), nothing is written to it.
+template <typename T, typename S, bool SCAN, bool PAGED, bool GIVEN = false>
 __device__ __forceinline__ void plain_tile_body(const S* __restrict__ page, int64_t n_rows, int op,
                                                 const PlainLit<T>& lit, uint32_t* __restrict__ bitmap32,
                                                 S* __restrict__ batch_values, uint32_t* __restrict__ batch_counts,
-                                                const BitmapWindow* win) {
+                                                const BitmapWindow* win, const uint32_t* __restrict__ given32 = nullptr,
+                                                const ChunkPage* pg = nullptr, int64_t total_dwords = 0) {
   using G = PlainGeom<S>;
   __shared__ __attribute__((aligned(16))) uint8_t lds_all[kWavesPerBlock * kPlainWaveBytes];
   const int lane = lane_id();
@@ -274,16 +277,29 @@ __device__ __forceinline__ void plain_tile_body(const S* __restrict__ page, int6
     if (next < tiles_end) plain_tile_load<S>(page, next, n_rows, lane, r);  // register prefetch
     wave_lds_fence();
 
-    uint32_t m = plain_lane_mask<T, S>(lds, lane, op, lit.v, lit.n);
-    if (lit.join != 0) {
-      const uint32_t m2 = plain_lane_mask<T, S>(lds, lane, lit.op2, &lit.v2, 1);
-      m = lit.join == 1 ? (m & m2) : (m | m2);
+    uint32_t m;
+    if constexpr (GIVEN) {
+      if (G::R == 32) {
+        m = window_fetch_at(given32, total_dwords, *pg, tile * 64 + lane, true);
+      } else {  // 1024-row tile: lanes 0..31 fetch its 32 dwords, lane l takes half of the dword of lane l / 2
+        const uint32_t dw = window_fetch_at(given32, total_dwords, *pg, tile * 32 + lane, lane < 32);
+        const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_bpermute((lane >> 1) << 2, (int)dw);
+        m = (mine >> (16 * (lane & 1))) & 0xFFFFu;
+      }
+    } else {
+      m = plain_lane_mask<T, S>(lds, lane, op, lit.v, lit.n);
+      if (lit.join != 0) {
+        const uint32_t m2 = plain_lane_mask<T, S>(lds, lane, lit.op2, &lit.v2, 1);
+        m = lit.join == 1 ? (m & m2) : (m | m2);
+      }
     }
     m &= plain_valid_mask<S>(tile, lane, n_rows);
 
     uint32_t bm = plain_pair_dword<S>(m);
     const int64_t d = G::R == 32 ? tile * 64 + lane : tile * 32 + (lane >> 1);
-    if constexpr (PAGED) {
+    if constexpr (GIVEN) {
+      (void)bm;
+    } else if constexpr (PAGED) {
       if (G::R == 32) {
         window_emit(*win, carry, d, bm, lit.combine);
       } else {  // dword k of the tile sits in lane 2k: bring it to lane k, 32 dwords per tile
@@ -338,6 +354,44 @@ __global__ __launch_bounds__(kThreads, 4) void plain_tile_pages_kernel(const Chu
   plain_tile_body<T, S, SCAN, true>(reinterpret_cast<const S*>(pg.data), pg.n_rows, op, lit, nullptr,
                                     SCAN ? batch_values + (int64_t)pg.batch0 * kRowsPerTile : nullptr,
                                     SCAN ? batch_counts + pg.batch0 : nullptr, &win);
+}
+
+// Late materialisation of a PLAIN chunk against a selection over the chunk's rows (all pages, one launch)
+template <typename S>
+__global__ __launch_bounds__(kThreads, 4) void plain_select_pages_kernel(const ChunkPage* __restrict__ pages, int64_t chunk_rows,
+                                                                         const uint32_t* __restrict__ given32,
+                                                                         S* __restrict__ batch_values,
+                                                                         uint32_t* __restrict__ batch_counts) {
+  const ChunkPage pg = pages[blockIdx.y];
+  BitmapWindow win = bitmap_window(nullptr, pg, chunk_rows);
+  win.shift = 0u;  // (nothing is emitted: every wave takes every n-th batch, whatever the page's offset)
+  PlainLit<S> lit;
+  __builtin_memset(&lit, 0, sizeof(lit));
+  plain_tile_body<S, S, true, true, true>(reinterpret_cast<const S*>(pg.data), pg.n_rows, 0, lit, nullptr,
+                                          batch_values + (int64_t)pg.batch0 * kRowsPerTile, batch_counts + pg.batch0, &win,
+                                          given32, &pg, bitmap_dwords(chunk_rows));
+}
+
+ips_status launch_plain_select_pages(int stride_bytes, const ChunkPage* d_pages, int n_pages, int64_t max_rows,
+                                     int64_t chunk_rows, const uint64_t* bitmap, void* batch_values,
+                                     uint32_t* batch_counts, hipStream_t s) {
+  const int64_t max_batches = (max_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const uint32_t* g = reinterpret_cast<const uint32_t*>(bitmap);
+  if (stride_bytes == 4) {
+    auto kern = plain_select_pages_kernel<uint32_t>;
+    const int gx = paged_grid_x(reinterpret_cast<const void*>(kern), max_batches, n_pages);
+    if (gx <= 0) return IPS_ERR_HIP;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)n_pages), dim3(kThreads), 0, s, d_pages, chunk_rows, g,
+                       reinterpret_cast<uint32_t*>(batch_values), batch_counts);
+  } else {
+    auto kern = plain_select_pages_kernel<uint64_t>;
+    const int gx = paged_grid_x(reinterpret_cast<const void*>(kern), max_batches, n_pages);
+    if (gx <= 0) return IPS_ERR_HIP;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)n_pages), dim3(kThreads), 0, s, d_pages, chunk_rows, g,
+                       reinterpret_cast<uint64_t*>(batch_values), batch_counts);
+  }
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
 }
 
 template <typename T, typename S, bool SCAN>

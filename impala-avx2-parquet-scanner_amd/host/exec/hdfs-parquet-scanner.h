@@ -61,6 +61,8 @@ class HdfsParquetScanner {
       }
     };
     virtual bool OpenChunk(ChunkHolder* h) = 0;
+    virtual const ips_dict* dict_handle() const = 0;  // NULL: a PLAIN column
+    virtual int slot_width() const = 0;               // bytes of a materialised value: 4 or 8
     // rows of the current page (DataPageHeader.num_values): what the device buffers of the page hold
     int64_t page_rows() const { return page_rows_; }
     int64_t num_buffered_values() const { return num_buffered_values_; }
@@ -275,6 +277,9 @@ class HdfsParquetScanner {
       col->d_batch_values = values.get();
       return true;
     }
+
+    virtual const ips_dict* dict_handle() const { return dict_decoder_ ? dict_decoder_->handle() : nullptr; }
+    virtual int slot_width() const { return ips_plain_stride(IpsTypeOf<T>::value); }
 
     // the current page (already resident) followed by the queued ones (uploaded here)
     virtual bool OpenChunk(ChunkHolder* h) {
@@ -634,17 +639,119 @@ class HdfsParquetScanner {
            bm.download(bitmap_words->data(), bitmap_words->size() * 8);
   }
 
-  // facade extra: AssembleRows' vector path (.cc:1101-1182) for num_rows rows of the current pages
-  // in a handful of launches -- the conjunct list (ips_eval_program), every slot's late
-  // materialisation against the resulting bitmap, and the row-major tuples (ips_assemble_tuples:
-  // InitTuple(template_tuple_) + each column's ReadValue at slot_desc->tuple_offset(), NULL
-  // indicator bits for OPTIONAL columns, descriptors.h:60-95).  Slots: 4- and 8-byte types.
   struct SlotDesc {
     int col_idx;            // column reader
     int tuple_offset;       // SlotDescriptor::tuple_offset()
     int null_byte_offset;   // null_indicator_offset().byte_offset (OPTIONAL columns)
     int null_bit_mask;      // null_indicator_offset().bit_mask
   };
+  // facade extra: AssembleRows' vector path (.cc:1101-1182) over EVERY page of the column chunks: the
+  // conjunct list (ips_eval_program_chunks), every slot's late materialisation against the resulting
+  // selection (ips_chunk_select: batches cut at the column's own page ends -> ips_batches_compact ->
+  // one dense array per slot) and the row-major tuples (ips_assemble_tuples with dense REQUIRED
+  // columns next to the selection's own batch counts).  REQUIRED slots (dictionary, PLAIN); a slot on
+  // an OPTIONAL column makes it return false (those go page by page through AssembleRowsFused).
+  bool AssembleRowsChunks(int tuple_size, const uint8_t* template_tuple, const std::vector<SlotDesc>& slots,
+                          std::vector<uint8_t>* tuples, int64_t* num_tuples) {
+    if (slots.empty() || slots.size() > IPS_TUPLE_MAX_COLS) return false;
+    lower_cols_.clear();
+    chunk_readers_.clear();
+    lower_chunks_ = true;
+    std::vector<ips_node> program;
+    bool lowered = true;
+    for (size_t i = 0; i < simple_predicates_.size() && lowered; ++i) {
+      lowered = simple_predicates_[i]->Lower(this, &program);
+      if (lowered && i > 0) { ips_node n; memset(&n, 0, sizeof(n)); n.kind = IPS_NODE_AND; program.push_back(n); }
+    }
+    lower_chunks_ = false;
+    if (!lowered) return false;
+    // a chunk per reader that the predicates or the slots touch
+    std::vector<std::unique_ptr<BaseColumnReader::ChunkHolder>> holders(column_readers_.size());
+    auto chunk_of = [&](int idx) -> const ips_chunk* {
+      if (!holders[(size_t)idx]) {
+        holders[(size_t)idx].reset(new BaseColumnReader::ChunkHolder());
+        if (!column_readers_[(size_t)idx]->OpenChunk(holders[(size_t)idx].get())) return nullptr;
+      }
+      return holders[(size_t)idx]->chunk;
+    };
+    std::vector<const ips_chunk*> pred_chunks;
+    for (int idx : chunk_readers_) {
+      const ips_chunk* c = chunk_of(idx);
+      if (!c) return false;
+      pred_chunks.push_back(c);
+    }
+    const ips_chunk* first = chunk_of(slots[0].col_idx);
+    if (!first) return false;
+    const int64_t n = ips_chunk_num_rows(first);
+    for (const ips_chunk* c : pred_chunks)
+      if (ips_chunk_num_rows(c) != n) return ips::ok(IPS_ERR_INVALID_ARG, "AssembleRowsChunks: the column chunks hold different row counts");
+    *num_tuples = 0;
+    tuples->clear();
+    if (n == 0) return true;
+    ips::DeviceBuffer bm((size_t)((n + 63) / 64 + 2) * 8);
+    if (program.empty()) {
+      if (!ips::ok(ips_bitmap_fill(bm.as<uint64_t>(), n, 1, nullptr), "ips_bitmap_fill")) return false;
+    } else {
+      const size_t ws_bytes = ips_chunk_program_workspace_bytes(program.data(), (int)program.size(), pred_chunks.data(), (int)pred_chunks.size());
+      if (ws_bytes > 0 && !program_workspace_.resize(ws_bytes)) return false;
+      if (!ips::ok(ips_eval_program_chunks(program.data(), (int)program.size(), pred_chunks.data(), (int)pred_chunks.size(),
+                                           bm.as<uint64_t>(), ws_bytes ? program_workspace_.get() : nullptr, nullptr),
+                   "ips_eval_program_chunks"))
+        return false;
+    }
+    const int64_t nb = (n + IPS_BATCH_ROWS - 1) / IPS_BATCH_ROWS;
+    ips::DeviceBuffer counts((size_t)nb * 4), d_count(16);
+    int64_t count = 0;
+    if (!ips::ok(ips_bitmap_batch_counts(bm.as<uint64_t>(), n, counts.as<uint32_t>(), nullptr), "ips_bitmap_batch_counts") ||
+        !ips::ok(ips_bitmap_count(bm.as<uint64_t>(), n, d_count.as<int64_t>(), nullptr), "ips_bitmap_count") ||
+        !d_count.download(&count, 8))
+      return false;
+    std::vector<std::unique_ptr<ips::DeviceBuffer>> keep;
+    std::vector<ips_tuple_column> cols(slots.size());
+    for (size_t i = 0; i < slots.size(); ++i) {
+      BaseColumnReader* r = column_readers_[(size_t)slots[i].col_idx].get();
+      if (r->max_def_level() > 0) return ips::ok(IPS_ERR_UNSUPPORTED, "AssembleRowsChunks: a slot on an OPTIONAL column");
+      const ips_chunk* c = chunk_of(slots[i].col_idx);
+      if (!c || ips_chunk_num_rows(c) != n) return false;
+      const int vw = r->slot_width();
+      const int64_t cb = ips_chunk_num_batches(c);
+      keep.emplace_back(new ips::DeviceBuffer((size_t)cb * IPS_BATCH_ROWS * vw));
+      ips::DeviceBuffer& values = *keep.back();
+      keep.emplace_back(new ips::DeviceBuffer((size_t)cb * 4 + 16));
+      ips::DeviceBuffer& cnts = *keep.back();
+      keep.emplace_back(new ips::DeviceBuffer((size_t)std::max<int64_t>(count, 1) * vw + 64));
+      ips::DeviceBuffer& dense = *keep.back();
+      keep.emplace_back(new ips::DeviceBuffer(ips_batches_workspace_bytes(cb * IPS_BATCH_ROWS) + 64));
+      ips::DeviceBuffer& ws = *keep.back();
+      ips::DeviceBuffer total(16);
+      if (!ips::ok(ips_chunk_select(c, r->dict_handle(), bm.as<uint64_t>(), values.get(), cnts.as<uint32_t>(), nullptr), "ips_chunk_select") ||
+          !ips::ok(ips_batches_compact(values.get(), cnts.as<uint32_t>(), cb * IPS_BATCH_ROWS, vw, dense.get(), total.as<int64_t>(),
+                                       ws.get(), nullptr), "ips_batches_compact"))
+        return false;
+      int64_t got = 0;
+      if (!total.download(&got, 8) || got != count) return ips::ok(IPS_ERR_HIP, "AssembleRowsChunks: a column materialised another number of rows than the selection holds");
+      memset(&cols[i], 0, sizeof(cols[i]));
+      cols[i].value_width = vw;
+      cols[i].tuple_offset = slots[i].tuple_offset;
+      cols[i].d_dense_values = dense.get();
+    }
+    ips::DeviceBuffer d_tuples((size_t)std::max<int64_t>(count, 1) * tuple_size + 64), d_total(16);
+    ips::DeviceBuffer ws(ips_assemble_workspace_bytes(n, 0) + 64);
+    if (!ips::ok(ips_assemble_tuples(cols.data(), (int)cols.size(), counts.as<uint32_t>(), n, tuple_size, template_tuple,
+                                     d_tuples.get(), d_total.as<int64_t>(), ws.get(), nullptr), "ips_assemble_tuples"))
+      return false;
+    int64_t total = 0;
+    if (!d_total.download(&total, 8) || total != count) return false;
+    tuples->assign((size_t)total * tuple_size, 0);
+    *num_tuples = total;
+    return total == 0 || d_tuples.download(tuples->data(), tuples->size());
+  }
+
+  // facade extra: AssembleRows' vector path (.cc:1101-1182) for num_rows rows of the current pages
+  // in a handful of launches -- the conjunct list (ips_eval_program), every slot's late
+  // materialisation against the resulting bitmap, and the row-major tuples (ips_assemble_tuples:
+  // InitTuple(template_tuple_) + each column's ReadValue at slot_desc->tuple_offset(), NULL
+  // indicator bits for OPTIONAL columns, descriptors.h:60-95).  Slots: 4- and 8-byte types.
   bool AssembleRowsFused(int64_t num_rows, int tuple_size, const uint8_t* template_tuple,
                          const std::vector<SlotDesc>& slots, std::vector<uint8_t>* tuples,
                          int64_t* num_tuples) {

@@ -836,6 +836,80 @@ static void TestLongInList() {
   CHECK(ips::sticky_status() == IPS_OK);
 }
 
+// Tuples straight from column chunks of several pages whose ends differ between the columns: the page
+// loop inside the launches, every slot materialised over its own page list, dense slots assembled.
+static void TestAssembleRowsChunks() {
+  const int n = 50021;
+  std::vector<int32_t> c0(n), c2(n);
+  std::vector<int64_t> c1(n);
+  DictEncoder<int32_t> e0;
+  DictEncoder<int64_t> e1;
+  for (int i = 0; i < n; ++i) {
+    c0[i] = (int32_t)(rnd() % 900) - 450;
+    c1[i] = (int64_t)(rnd() % 77) * 1000003ll - 5;
+    c2[i] = (int32_t)(rnd() % 4000) - 2000;
+    e0.Put(c0[i]);
+    e1.Put(c1[i]);
+  }
+  std::vector<uint8_t> d0((size_t)e0.dict_encoded_size() + 8), d1((size_t)e1.dict_encoded_size() + 8);
+  e0.WriteDict(d0.data());
+  e1.WriteDict(d1.data());
+  auto page32 = [&](int lo, int hi) {
+    e0.ClearIndices();
+    for (int i = lo; i < hi; ++i) e0.Put(c0[(size_t)i]);
+    std::vector<uint8_t> b(1 << 19);
+    const int len = e0.WriteData(b.data(), (int)b.size());
+    CHECK(len > 0);
+    b.resize((size_t)len);
+    return b;
+  };
+  auto page64 = [&](int lo, int hi) {
+    e1.ClearIndices();
+    for (int i = lo; i < hi; ++i) e1.Put(c1[(size_t)i]);
+    std::vector<uint8_t> b(1 << 19);
+    const int len = e1.WriteData(b.data(), (int)b.size());
+    CHECK(len > 0);
+    b.resize((size_t)len);
+    return b;
+  };
+  const int b0[] = {0, 7001, 30000, n}, b1[] = {0, 20011, n}, b2[] = {0, 33, 4100, 41000, n};
+  std::vector<std::vector<uint8_t>> p0, p1;
+  for (int k = 0; k < 3; ++k) p0.push_back(page32(b0[k], b0[k + 1]));
+  for (int k = 0; k < 2; ++k) p1.push_back(page64(b1[k], b1[k + 1]));
+  std::vector<uint8_t> plain((size_t)n * 4);
+  memcpy(plain.data(), c2.data(), plain.size());
+  HdfsParquetScanner s;
+  s.AddDictionaryColumn<int32_t>(d0.data(), e0.dict_encoded_size(), p0[0].data(), (int)p0[0].size(), b0[1] - b0[0]);
+  s.AddDictionaryColumn<int64_t>(d1.data(), e1.dict_encoded_size(), p1[0].data(), (int)p1[0].size(), b1[1] - b1[0]);
+  s.AddPlainColumn<int32_t>(plain.data(), b2[1]);
+  for (int k = 1; k < 3; ++k) s.AddDataPage(0, p0[(size_t)k].data(), (int)p0[(size_t)k].size(), b0[k + 1] - b0[k]);
+  s.AddDataPage(1, p1[1].data(), (int)p1[1].size(), b1[2] - b1[1]);
+  for (int k = 1; k < 4; ++k) s.AddDataPage(2, plain.data() + (size_t)b2[k] * 4, (b2[k + 1] - b2[k]) * 4, b2[k + 1] - b2[k]);
+  s.AddSimplePredicate(s.Own(new AndOperate(s.Own(new GeOperate<int32_t>(0, -100)), s.Own(new LtOperate<int32_t>(0, 120)))));
+  s.AddSimplePredicate(s.Own(new LeOperate<int64_t>(1, 30 * 1000003ll)));
+  // tuple: [int64 c1 @0][int32 c0 @8][int32 c2 @12][4 bytes of template @16] = 20 bytes
+  const int ts = 20;
+  uint8_t tmpl[ts];
+  for (int i = 0; i < ts; ++i) tmpl[i] = (uint8_t)(0xA0 + i);
+  std::vector<HdfsParquetScanner::SlotDesc> slots = {{1, 0, 0, 0}, {0, 8, 0, 0}, {2, 12, 0, 0}};
+  std::vector<uint8_t> tuples;
+  int64_t nt = 0;
+  CHECK(s.AssembleRowsChunks(ts, tmpl, slots, &tuples, &nt));
+  int64_t exp = 0, wrong = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!(c0[(size_t)i] >= -100 && c0[(size_t)i] < 120 && c1[(size_t)i] <= 30 * 1000003ll)) continue;
+    if (exp < nt) {
+      const uint8_t* t = tuples.data() + (size_t)exp * ts;
+      int64_t v1; int32_t v0, v2;
+      memcpy(&v1, t, 8); memcpy(&v0, t + 8, 4); memcpy(&v2, t + 12, 4);
+      wrong += v1 != c1[(size_t)i] || v0 != c0[(size_t)i] || v2 != c2[(size_t)i] || memcmp(t + 16, tmpl + 16, 4) != 0;
+    }
+    ++exp;
+  }
+  CHECK(nt == exp && exp > 1000 && wrong == 0);
+  CHECK(ips::sticky_status() == IPS_OK);
+}
+
 static void TestProgramWithTemporaryBitmap() {
   const int n = 70001;
   std::vector<uint32_t> a(n), b(n);
@@ -905,6 +979,7 @@ int main() {
   TestColumnChunkStream();
   TestAssembleRowsFused();
   TestLongInList();
+  TestAssembleRowsChunks();
   CHECK(ips::sticky_status() == IPS_OK);
   printf("facade_test: %d checks, %d failed\n", g_checks, g_fail);
   return g_fail ? 1 : 0;

@@ -195,7 +195,10 @@ typedef struct {
    * tuple[null_byte_offset] |= null_bit_mask (SlotDescriptor::null_indicator_offset(),
    * descriptors.h:60-71) and its slot keeps the template's bytes. */
   const void* d_dense_values;
-  const uint64_t* d_nonnull_flags;
+  const uint64_t* d_nonnull_flags; /* NULL with d_dense_values set: a REQUIRED column given as ONE dense array
+                                      (tuple i takes value i) instead of batches -- what ips_chunk_select +
+                                      ips_batches_compact produce over a page list, whose batches are cut at
+                                      the column's own page ends and cannot share d_batch_counts */
   int32_t null_byte_offset;
   int32_t null_bit_mask;
 } ips_tuple_column;
@@ -509,8 +512,12 @@ ips_status ips_chunk_plain_scan(const ips_chunk* chunk, ips_op op, const void* l
                                 ips_op op2, const void* literal2, ips_semantics semantics,
                                 uint64_t* d_bitmap, void* d_batch_values, uint32_t* d_batch_counts,
                                 ips_stream stream);
-/* Late materialisation of a REQUIRED FLE / dictionary chunk against a selection over the chunk's
- * rows (ips_fle_select / ips_dict_select with the page loop inside; dict NULL: the FLE values). */
+/* Late materialisation of a REQUIRED chunk against a selection over the chunk's rows: ips_fle_select /
+ * ips_dict_select / ips_plain_select with the page loop inside (dict NULL: the FLE values / the PLAIN
+ * slots of ips_plain_stride bytes).  The batches are cut at the column's own page ends:
+ * ips_batches_compact turns them into the dense array that ips_assemble_tuples takes as a dense
+ * REQUIRED column (ips_tuple_column.d_dense_values with d_nonnull_flags NULL), next to batch counts
+ * of the selection itself (ips_bitmap_batch_counts). */
 ips_status ips_chunk_select(const ips_chunk* chunk, const ips_dict* dict, const uint64_t* d_bitmap,
                             void* d_batch_values, uint32_t* d_batch_counts, ips_stream stream);
 

@@ -260,6 +260,11 @@ def test_chunk_plain_scan_pages(capi, O):
         exp = (vals >= lo) & (vals <= hi)
         assert np.array_equal(words(bitmap), pack(exp))
         assert np.array_equal(chunk.compact(bvals, counts).cpu().numpy().view(vals.dtype), vals[exp])
+        # ReadValue(skip) against selections over the chunk's rows (ips_chunk_select on PLAIN pages)
+        for sel in (exp, rng.random(n) < 0.02, rng.random(n) < 0.7, np.ones(n, bool)):
+            bm = torch.from_numpy(pack(sel).view(np.int64).copy()).cuda()
+            bv, cnt = chunk.select(bm)
+            assert np.array_equal(chunk.compact(bv, cnt).cpu().numpy().view(vals.dtype), vals[sel]), t
         chunk.close()
 
 
