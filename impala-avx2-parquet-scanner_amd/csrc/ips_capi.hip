@@ -53,13 +53,17 @@ int device_cus() {
 // slowest CU; smaller work shares let the dispatcher even that out (round 1: 4x, +3..6 % on the
 // w=32 scan and predicate kernels; end of round 2, with the narrow scans at 8 waves per SIMD: 8x is
 // neutral at w=32 and 3-5 % faster at w <= 16, 12x and more cost the early-pruning predicate its
-// prefetch).  IPS_GRID_MULT overrides it (dev knob).
-int grid_mult() {
-  static int m = [] { const char* e = dev_env("IPS_GRID_MULT"); int v = e ? atoi(e) : 8; return v > 0 ? v : 8; }();
-  return m;
+// prefetch).  Round 3: the predicate-only kernels and the one-pass chain, whose waves spend a few
+// hundred instructions per sub-tile, run best with shares of one or two sub-tiles per wave (kind 1 /
+// 2 below; tools/ab/grid_mult_sweep.py).  Dev builds read IPS_GRID_MULT / _PRED / _CHAIN on every call.
+int grid_mult(int kind) {
+  const char* e = dev_env(kind == kGridPred ? "IPS_GRID_MULT_PRED" : kind == kGridChain ? "IPS_GRID_MULT_CHAIN" : "IPS_GRID_MULT");
+  const int v = e ? atoi(e) : 0;
+  if (v > 0) return v;
+  return kind == kGridPred ? IPS_GRID_MULT_PRED : kind == kGridChain ? IPS_GRID_MULT_CHAIN : 8;
 }
 
-int grid_for_tiles(const void* kernel, int64_t tiles) {
+int grid_for_tiles(const void* kernel, int64_t tiles, int kind) {
   int cus = device_cus();
   if (cus <= 0) {
     set_error("no HIP device");
@@ -80,7 +84,7 @@ int grid_for_tiles(const void* kernel, int64_t tiles) {
   }
   int64_t want = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
   if (want < 1) want = 1;
-  int64_t cap = (int64_t)cus * per_cu * grid_mult();
+  int64_t cap = (int64_t)cus * per_cu * grid_mult(kind);
   if (want <= cap) return (int)want;
   // Even shares: with 'cap' blocks and want = 1.33 * cap, a third of the blocks would make two
   // rounds and the rest one -- the launch lasts two rounds for 1.33 rounds of work (a 2^25-row

@@ -1,0 +1,54 @@
+// ips_chain.h -- arguments of the one-pass conjunct chain (ips_chain.hip), filled by ips_eval_program.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ips.h"
+
+namespace ips {
+
+constexpr int kChainWMaxOps = 6;
+constexpr int kChainWMaxSlots = 16;  // 16-byte loads per lane and stripe
+enum ChainKind { kChainSingle = 0, kChainPair = 1, kChainIn = 2 };
+
+// one operand: a comparison, two comparisons on one column, or a short IN list
+struct ChainOpW {
+  int32_t w;             // 1..32
+  int32_t kind;          // ChainKind
+  int32_t op, op2;       // ips_op of the comparison(s)
+  int32_t join;          // pair: 1 AND / 2 OR of the two comparisons
+  int32_t combine;       // 0 first operand, 1 AND / 2 OR into the accumulator
+  uint32_t c1, c2;
+  int32_t n_in;          // IN: members in in_consts
+  int32_t img_dw;        // dword offset of the operand's plane image in the wave's LDS region
+  uint32_t in_consts[16];
+  // plane masks of c1 / c2 (0 or ~0 per plane, w <= 16): they arrive in scalar registers with two wide
+  // scalar loads instead of one scalar bit-field extract per plane and constant
+  uint32_t m1[16], m2[16];
+  uint32_t pad[6];       // 256 bytes per operand
+};
+static_assert(sizeof(ChainOpW) == 256, "operand descriptors are indexed by a shift");
+
+// one load slot of a stripe: 64 consecutive 16-byte chunks of ONE operand's sub-tile, so that
+// everything about a slot is wave-uniform and arrives with one scalar load
+struct ChainSlot {
+  uint32_t rsrc[4];      // buffer resource over the operand's whole column (its bytes bound every load)
+  uint32_t first_byte;   // byte offset of the slot's first chunk inside the sub-tile
+  uint32_t tile_bytes;   // 256 w: bytes of a sub-tile of this operand
+  uint32_t inv_w;        // floor(2^32 / w) + 1
+  int32_t img_dw;        // the operand's plane image
+};
+
+struct ChainArgsW {
+  ChainSlot slots[kChainWMaxSlots];
+  ChainOpW ops[kChainWMaxOps];
+  int32_t n_ops, n_slots;
+  int32_t image_dwords;  // per wave
+  int32_t reserved;
+};
+
+// IPS_ERR_UNSUPPORTED: the chain does not fit the kernel (more than kChainWMaxSlots load slots, a
+// column of 4 GiB or more) -- the caller falls back to the per-operand plan
+ips_status launch_chain_w(ChainArgsW& a, const void* const* enc, int64_t n_rows, uint32_t* bitmap32, hipStream_t s);
+
+}  // namespace ips

@@ -1,0 +1,294 @@
+// ips_chain.hip -- a conjunct chain over REQUIRED FLE columns in ONE pass.
+//
+// EvalSimplePredicates' conjunct list (hdfs-parquet-scanner.cc:1857-1862) and any left-deep AND / OR
+// chain of operands: every operand is a comparison, a pair of comparisons on one column (BETWEEN,
+// simple-predicates.h:145-153) or a short IN list (FleDecoder::In, fle-encoding.h:8283-8290).  The
+// per-operand plan runs one launch per operand and folds the results through the bitmap (2 bits of
+// read-modify-write per row and operand: on the Q6 shape 2.03 GB moved for 1.73 GB of algorithmic
+// bytes).  Here a wave keeps a 2048-row stripe's result in a register while it walks the operands:
+// every column is read once and the bitmap is written once.
+//
+// The sub-tiles of all operands for the same 2048 rows form one STRIPE; its 16-byte chunks are dealt
+// to LOAD SLOTS of 64 chunks, every slot inside one operand (w = 12: three slots, w = 6: two, w = 4:
+// one).  A slot's descriptor -- a buffer resource over the operand's column prepared by the host, the
+// slot's place in the sub-tile and in LDS -- is wave-uniform and arrives as one 32-byte scalar load,
+// the loads and the staging into the operands' plane images take the width at run time (a handful of
+// vector ops per slot), and the whole NEXT stripe is in flight in the slot registers while the
+// current one is evaluated.  The evaluation of an operand is reached through a wave-uniform switch on
+// its width: compile-time-width code, the building blocks of the stand-alone predicate kernels.
+//
+// Round 2's kernel (fle_chain_kernel) evaluated with run-time widths and re-derived resources per
+// slot: 519 scalar instructions per stripe, a tie with the three launches.
+#include "ips_device.h"
+#include "ips_host.h"
+#include "ips_chain.h"
+
+#include <map>
+#include <mutex>
+#include <type_traits>
+
+namespace ips {
+
+// f(std::integral_constant<int, W>) for W == w; widths beyond MAXW are not compiled into the kernel
+template <int MAXW, typename F>
+__device__ __forceinline__ void width_switch(int w, F&& f) {
+  switch (w) {
+#define IPS_CASE(W)                                               \
+  case W:                                                         \
+    if constexpr (W <= MAXW) f(std::integral_constant<int, W>{}); \
+    break;
+    IPS_CASE(1) IPS_CASE(2) IPS_CASE(3) IPS_CASE(4) IPS_CASE(5) IPS_CASE(6) IPS_CASE(7) IPS_CASE(8)
+    IPS_CASE(9) IPS_CASE(10) IPS_CASE(11) IPS_CASE(12) IPS_CASE(13) IPS_CASE(14) IPS_CASE(15) IPS_CASE(16)
+    IPS_CASE(17) IPS_CASE(18) IPS_CASE(19) IPS_CASE(20) IPS_CASE(21) IPS_CASE(22) IPS_CASE(23) IPS_CASE(24)
+    IPS_CASE(25) IPS_CASE(26) IPS_CASE(27) IPS_CASE(28) IPS_CASE(29) IPS_CASE(30) IPS_CASE(31) IPS_CASE(32)
+#undef IPS_CASE
+    default: break;
+  }
+}
+
+// The descriptors are read from the kernel-argument segment through a constant-address-space pointer:
+// scalar loads at run-time indices.  (Indexing the by-value argument itself made the compiler copy
+// the whole structure to scratch.)
+typedef const ChainArgsW __attribute__((address_space(4))) * ChainArgsK;
+typedef const uint32_t __attribute__((address_space(4))) * ConstsK;
+struct ChainStep {  // one operand, in scalar registers
+  int w, kind, op, op2, join, combine, n_in, img_dw;
+  uint32_t c1, c2;
+  ConstsK in_consts, m1, m2;
+};
+__device__ __forceinline__ ChainStep chain_step(ChainArgsK a, int i) {
+  ChainStep o;
+  o.w = a->ops[i].w;
+  o.kind = a->ops[i].kind;
+  o.op = a->ops[i].op;
+  o.op2 = a->ops[i].op2;
+  o.join = a->ops[i].join;
+  o.combine = a->ops[i].combine;
+  o.n_in = a->ops[i].n_in;
+  o.img_dw = a->ops[i].img_dw;
+  o.c1 = a->ops[i].c1;
+  o.c2 = a->ops[i].c2;
+  o.in_consts = a->ops[i].in_consts;
+  o.m1 = a->ops[i].m1;
+  o.m2 = a->ops[i].m2;
+  return o;
+}
+
+// the operand's rows of this lane (MSB-first, like every predicate building block).  Operands of up
+// to 16 bits take their constants as plane masks from the descriptor (ChainOpW::m1 / m2).
+template <int W>
+__device__ __forceinline__ uint32_t chain_eval(const uint32_t* img, int lane, const ChainStep& o) {
+  if (o.kind == kChainPair) {  // wave-uniform
+    if constexpr (W > 16) {
+      uint32_t r1, r2;
+      pred_pair_from_lds(img, W, lane, o.op, o.c1, o.op2, o.c2, &r1, &r2);
+      return o.join == 1 ? (r1 & r2) : (r1 | r2);
+    } else {
+      uint32_t p[W];
+      planes_from_lds<W>(img, lane, p);
+      uint32_t r1, r2;
+      if (o.op != 0 && o.op2 != 0) {  // two borrow chains (BETWEEN and friends)
+        uint32_t a1 = borrow_init(o.op), a2 = borrow_init(o.op2);
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          a1 = borrow_step(a1, p[k], o.m1[k]);
+          a2 = borrow_step(a2, p[k], o.m2[k]);
+        }
+        r1 = borrow_select(a1, o.op);
+        r2 = borrow_select(a2, o.op2);
+      } else {
+        const bool eq1 = o.op == 0, eq2 = o.op2 == 0;
+        uint32_t a1 = eq1 ? ~0u : borrow_init(o.op), a2 = eq2 ? ~0u : borrow_init(o.op2);
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          a1 = eq1 ? eq_step(a1, p[k], o.m1[k]) : borrow_step(a1, p[k], o.m1[k]);
+          a2 = eq2 ? eq_step(a2, p[k], o.m2[k]) : borrow_step(a2, p[k], o.m2[k]);
+        }
+        r1 = eq1 ? a1 : borrow_select(a1, o.op);
+        r2 = eq2 ? a2 : borrow_select(a2, o.op2);
+      }
+      return o.join == 1 ? (r1 & r2) : (r1 | r2);
+    }
+  }
+  if (o.kind == kChainIn) {
+    if constexpr (W <= 16) {
+      uint32_t p[W];
+      planes_from_lds<W>(img, lane, p);
+      return pred_in_from_regs<W>(p, o.in_consts, o.n_in);
+    } else {
+      return pred_in_from_lds(img, W, lane, o.in_consts, o.n_in);
+    }
+  }
+  if constexpr (W > 16) {  // streamed from LDS eight planes at a time: no 32 plane registers next to the slots
+    return pred_single_from_lds(img, W, lane, o.op, o.c1);
+  } else {
+    uint32_t p[W];
+    planes_from_lds<W>(img, lane, p);
+    if (o.op == 0) {
+      uint32_t eq = ~0u;
+#pragma unroll
+      for (int k = 0; k < W; ++k) eq = eq_step(eq, p[k], o.m1[k]);
+      return eq;
+    }
+    uint32_t b = borrow_init(o.op);
+#pragma unroll
+    for (int k = 0; k < W; ++k) b = borrow_step(b, p[k], o.m1[k]);
+    return borrow_select(b, o.op);
+  }
+}
+
+// Instantiated per (load slots, widest operand): the slot registers and the widest compiled-in
+// predicate body set the register allocation, i.e. the waves per SIMD
+constexpr int chain_min_waves(int ltot, int maxw) {
+  return maxw <= 16 ? (ltot <= 4 ? 8 : ltot <= 6 ? 5 : ltot <= 8 ? 4 : 3) : (ltot <= 8 ? 4 : 3);
+}
+
+// (the kernel's first parameter is read through the kernarg segment pointer: it sits at offset 0)
+template <int LTOT, int MAXW>
+__global__ __launch_bounds__(kThreads, chain_min_waves(LTOT, MAXW)) void fle_chain_w_kernel(
+    ChainArgsW a_by_value, int64_t n_rows, uint32_t* __restrict__ bitmap32) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
+  (void)a_by_value;
+  const ChainArgsK a = (ChainArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+  const int lane = lane_id();
+  const int wave = wave_id();
+  uint32_t* lds32 = lds_all + wave * a->image_dwords;
+  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t bm_dwords = bitmap_dwords(n_rows);
+  const int n_ops = a->n_ops;
+  const uint32_t lane_byte = (uint32_t)lane * 16u;
+  int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+
+  u32x4 r[LTOT];
+  // slot i of stripe t: chunks beyond the sub-tile's 16 w take an offset outside every column (zeros, no
+  // traffic); bytes beyond the column's end are outside the resource
+  auto load_slot = [&](int i, int64_t t) {
+    const uint32_t first = a->slots[i].first_byte, tile_bytes = a->slots[i].tile_bytes;
+    const u32x4 words = {a->slots[i].rsrc[0], a->slots[i].rsrc[1], a->slots[i].rsrc[2], a->slots[i].rsrc[3]};
+    __amdgpu_buffer_rsrc_t rsrc;  // prepared by the host
+    __builtin_memcpy(&rsrc, &words, 16);
+    const uint32_t in_tile = first + lane_byte;
+    const uint32_t off = in_tile < tile_bytes ? (uint32_t)t * tile_bytes + in_tile : 0xFFFFFFF0u;
+    r[i] = buffer_load16<true>(rsrc, off);
+  };
+  auto stage_slot = [&](int i) {
+    const uint32_t first = a->slots[i].first_byte, tile_bytes = a->slots[i].tile_bytes;
+    const uint32_t in_tile = first + lane_byte;
+    if (in_tile < tile_bytes) {
+      const uint32_t w = tile_bytes >> 8;
+      const uint32_t wi = in_tile >> 3;  // first of the chunk's two words
+      const uint32_t blk = __umulhi(wi, a->slots[i].inv_w);
+      uint32_t* dst = lds32 + a->slots[i].img_dw + 2 * (blk * (w | 1u) + (wi - blk * w));
+      const u32x2 lo = {r[i].x, r[i].y}, hi = {r[i].z, r[i].w};
+      *reinterpret_cast<u32x2*>(dst) = lo;
+      *reinterpret_cast<u32x2*>(dst + 2) = hi;
+    }
+  };
+  // (slots beyond n_slots have tile_bytes = 0: no lane stages them, their loads are out of range -- no
+  // wave-uniform branch per slot, so the descriptors' scalar loads are batched)
+  if (tile < tiles) {
+#pragma unroll
+    for (int i = 0; i < LTOT; ++i) load_slot(i, tile);
+  }
+  while (tile < tiles) {
+    const int64_t next = tile + stride;
+    // all slots are staged before the first load of the next stripe is issued: a load in between would
+    // sit in front of the older ones in vmcnt's order and every staging step would wait for it
+#pragma unroll
+    for (int i = 0; i < LTOT; ++i) stage_slot(i);
+    if (next < tiles) {  // the slot registers are free: the whole next stripe
+#pragma unroll
+      for (int i = 0; i < LTOT; ++i) load_slot(i, next);
+    }
+    wave_lds_fence();
+    uint32_t acc = 0u;
+#pragma unroll 1
+    for (int i = 0; i < n_ops; ++i) {
+      const ChainStep o = chain_step(a, i);
+      uint32_t sel = 0u;
+      width_switch<MAXW>(o.w, [&](auto W) { sel = chain_eval<decltype(W)::value>(lds32 + o.img_dw, lane, o); });
+      acc = o.combine == 0 ? sel : o.combine == 1 ? (acc & sel) : (acc | sel);
+    }
+    const uint32_t bm = finish_bitmap_dword(acc, tile, lane, n_rows);
+    const int64_t d = tile * 64 + lane;
+    if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, bm);
+    wave_lds_fence();  // the images are rewritten by the next stripe
+    tile = next;
+  }
+}
+
+template <int LTOT, int MAXW>
+static ips_status launch_chain_w_class(const ChainArgsW& a, int64_t n_rows, uint32_t* bitmap32, hipStream_t s) {
+  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  auto kern = fle_chain_w_kernel<LTOT, MAXW>;
+  const size_t lds = (size_t)kWavesPerBlock * a.image_dwords * 4;
+  // resident size: the dynamic image is not known to the occupancy cache of grid_for_tiles
+  static std::mutex mu;
+  static std::map<size_t, int> resident;  // per instantiation: image bytes -> workgroups per CU
+  int per_cu = 0;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = resident.find(lds);
+    if (it != resident.end()) per_cu = it->second;
+  }
+  if (per_cu == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kThreads, lds) != hipSuccess || per_cu <= 0)
+      per_cu = 2;
+    std::lock_guard<std::mutex> lk(mu);
+    resident[lds] = per_cu;
+  }
+  const int64_t want = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int64_t cap = (int64_t)device_cus() * per_cu * grid_mult(kGridChain);
+  const int64_t rounds = (want + cap - 1) / cap;
+  const int grid = (int)(want <= cap ? want : (want + rounds - 1) / rounds);
+  if (grid <= 0) return IPS_ERR_HIP;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, a, n_rows, bitmap32);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+// a.ops[0..n_ops) filled by the caller (w, kind, operators, constants, combine); enc[i] = operand i's column
+ips_status launch_chain_w(ChainArgsW& a, const void* const* enc, int64_t n_rows, uint32_t* bitmap32, hipStream_t s) {
+  int slots = 0, img = 0;
+  const int64_t n_blocks = (n_rows + 63) / 64;
+  for (int i = 0; i < a.n_ops; ++i) {
+    const int w = a.ops[i].w;
+    const int64_t bytes = n_blocks * w * 8;
+    if (bytes >= 0xFFFFFFF0ll) return IPS_ERR_UNSUPPORTED;
+    a.ops[i].img_dw = img;
+    for (int k = 0; k < 16; ++k) {
+      a.ops[i].m1[k] = ((a.ops[i].c1 >> k) & 1u) ? ~0u : 0u;
+      a.ops[i].m2[k] = ((a.ops[i].c2 >> k) & 1u) ? ~0u : 0u;
+    }
+    for (int c = 0; c < 16 * w; c += kWave) {
+      if (slots == kChainWMaxSlots) return IPS_ERR_UNSUPPORTED;
+      ChainSlot& sl = a.slots[slots++];
+      const uint64_t base = reinterpret_cast<uint64_t>(enc[i]);
+      sl.rsrc[0] = (uint32_t)base;
+      sl.rsrc[1] = (uint32_t)(base >> 32) & 0xFFFFu;
+      sl.rsrc[2] = (uint32_t)bytes;
+      sl.rsrc[3] = kBufferRsrcDword3;
+      sl.first_byte = (uint32_t)c * 16u;
+      sl.tile_bytes = 256u * (uint32_t)w;
+      sl.inv_w = (uint32_t)(0x100000000ull / (uint64_t)w) + 1u;
+      sl.img_dw = img;
+    }
+    img += plane_tile_bytes(w) / 4;
+  }
+  a.n_slots = slots;
+  a.image_dwords = img;
+  if ((size_t)kWavesPerBlock * img * 4 > 64 * 1024) return IPS_ERR_UNSUPPORTED;
+  int maxw = 0;
+  for (int i = 0; i < a.n_ops; ++i) maxw = a.ops[i].w > maxw ? a.ops[i].w : maxw;
+#define IPS_CHAIN_CLASS(L)                                                                  \
+  if (slots <= L)                                                                           \
+    return maxw <= 16 ? launch_chain_w_class<L, 16>(a, n_rows, bitmap32, s)                 \
+                      : launch_chain_w_class<L, 32>(a, n_rows, bitmap32, s);
+  IPS_CHAIN_CLASS(2) IPS_CHAIN_CLASS(4) IPS_CHAIN_CLASS(6) IPS_CHAIN_CLASS(8) IPS_CHAIN_CLASS(12)
+#undef IPS_CHAIN_CLASS
+  return maxw <= 16 ? launch_chain_w_class<16, 16>(a, n_rows, bitmap32, s)
+                    : launch_chain_w_class<16, 32>(a, n_rows, bitmap32, s);
+}
+
+}  // namespace ips

@@ -79,11 +79,13 @@ __device__ __forceinline__ BitmapWindow bitmap_window(uint32_t* bitmap32, const 
 
 // one dword of the chunk-wide bitmap: 'mask' = the bits this lane owns, 'val' its values there
 // (val & ~mask == 0).  combine: 0 store, 1 AND into, 2 OR into.
-__device__ __forceinline__ void window_put(uint32_t* p, uint32_t val, uint32_t mask, int combine, uint32_t coherent) {
+// 'old': the dword's present value when the caller has fetched it ahead (window_operand), else NULL.
+__device__ __forceinline__ void window_put(uint32_t* p, uint32_t val, uint32_t mask, int combine, uint32_t coherent,
+                                           const uint32_t* old = nullptr) {
   if (mask == 0u) return;
   if (mask == ~0u) {
-    if (combine == 1) val &= *p;
-    else if (combine == 2) val |= *p;
+    if (combine == 1) val &= old ? *old : *p;
+    else if (combine == 2) val |= old ? *old : *p;
     window_store(p, val, coherent);
     return;
   }
@@ -128,8 +130,17 @@ __device__ __forceinline__ void window_flush(const BitmapWindow& w, WindowCarry&
 // One run: lane l holds the page-relative dword d = d0 + l ('bm': bit j <-> row 32 d + j of the page)
 // for l <= last_lane (63, or 31 when only half the wave holds dwords); every lane of the wave calls
 // it.  combine: 0 store, 1 AND into, 2 OR into.
+// The dword an AND-into / OR-into launch will combine lane dword d with, fetched ahead (with the
+// sub-tile's register prefetch) when the window is aligned; 'have' says whether it was.
+__device__ __forceinline__ bool window_has_operand(const BitmapWindow& w, int combine) {
+  return combine != 0 && w.shift == 0u;  // wave-uniform
+}
+__device__ __forceinline__ uint32_t window_operand(const BitmapWindow& w, int64_t d) {
+  return d * 32 < w.n_rows ? w.base[d] : 0u;
+}
+
 __device__ __forceinline__ void window_emit(const BitmapWindow& w, WindowCarry& cy, int64_t d, uint32_t bm, int combine,
-                                            int last_lane = kWave - 1) {
+                                            int last_lane = kWave - 1, const uint32_t* old = nullptr) {
   const int lane = (int)(threadIdx.x & (kWave - 1));
   const int64_t valid = w.n_rows - d * 32;
   const uint32_t vm = lane > last_lane ? 0u : valid >= 32 ? ~0u : valid <= 0 ? 0u : ((1u << valid) - 1u);
@@ -166,7 +177,7 @@ __device__ __forceinline__ void window_emit(const BitmapWindow& w, WindowCarry& 
   }
   const bool tail = w.own_tail && d == w.tail_dword && mask != 0u;  // zeros behind the chunk's last row
   if (tail) mask |= w.tail_mask;
-  window_put(w.base + d, val, mask, combine, w.coherent);
+  window_put(w.base + d, val, mask, combine, w.coherent, w.shift == 0u ? old : nullptr);
   if (tail && w.tail_extra && combine != 2) window_store(w.base + d + 1, 0u, w.coherent);
 }
 

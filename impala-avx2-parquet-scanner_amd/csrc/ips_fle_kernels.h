@@ -633,12 +633,28 @@ __device__ __forceinline__ void fle_pred_body(const uint64_t* __restrict__ enc, 
   __shared__ uint32_t in_table[kInTable ? InTable<W>::kDwords : 1];
   if constexpr (kInTable) in_table_build<W>(in_table, args);
 
+  // The dword an AND-into / OR-into launch combines with travels with the register prefetch of its
+  // sub-tile.  (Loaded where it is used -- after the predicate -- it put a whole memory round trip,
+  // and a vmcnt(0) that also waited out the prefetched planes, at the end of every sub-tile.)
+  auto combine_operand = [&](int64_t t) -> uint32_t {
+    const int64_t d = t * 64 + lane;
+    if constexpr (PAGED) return window_has_operand(*win, args.combine) ? window_operand(*win, d) : 0u;
+    return (args.combine != 0 && d < bm_dwords) ? bitmap32[d] : 0u;
+  };
   u32x4 r[L];
-  if (tile < tiles) tile_load<L>(enc, tile, W, total_words, lane, r);
+  uint32_t old = 0u;
+  if (tile < tiles) {
+    old = combine_operand(tile);
+    tile_load<L>(enc, tile, W, total_words, lane, r);
+  }
   while (tile < tiles) {
     tile_to_lds<L>(lds32, W, lane, r);
     const int64_t next = tile + stride;
-    if (next < tiles) tile_load<L>(enc, next, W, total_words, lane, r);  // register prefetch
+    const uint32_t old_now = old;
+    if (next < tiles) {  // register prefetch
+      old = combine_operand(next);
+      tile_load<L>(enc, next, W, total_words, lane, r);
+    }
     wave_lds_fence();
     uint32_t sel;
     if (KIND == kPredSingle) {
@@ -666,10 +682,10 @@ __device__ __forceinline__ void fle_pred_body(const uint64_t* __restrict__ enc, 
     uint32_t bm = finish_bitmap_dword(sel, tile, lane, n_rows);
     const int64_t d = tile * 64 + lane;
     if constexpr (PAGED) {
-      window_emit(*win, carry, d, bm, args.combine);
+      window_emit(*win, carry, d, bm, args.combine, kWave - 1, window_has_operand(*win, args.combine) ? &old_now : nullptr);
     } else if (d < bm_dwords) {
-      if (args.combine == 1) bm &= bitmap32[d];
-      else if (args.combine == 2) bm |= bitmap32[d];
+      if (args.combine == 1) bm &= old_now;
+      else if (args.combine == 2) bm |= old_now;
       IPS_BITMAP_STORE(bitmap32 + d, bm);
     }
     wave_lds_fence();  // LDS region is reused by the next sub-tile
@@ -1364,10 +1380,20 @@ __device__ __forceinline__ void fle_pred32_early_body(const uint64_t* __restrict
     tiles = sh.end;
   }
   bool with_low = false;  // wave-uniform: the previous sub-tile needed the low planes
+  auto combine_operand = [&](int64_t t) -> uint32_t {  // see fle_pred_body
+    const int64_t d = t * 64 + lane;
+    if constexpr (PAGED) return window_has_operand(*win, args.combine) ? window_operand(*win, d) : 0u;
+    return (args.combine != 0 && d < bm_dwords) ? bitmap32[d] : 0u;
+  };
   u32x4 rh[4], rl[4];
-  if (tile < tiles) load_half(tile, 1, rh);
+  uint32_t old = 0u;
+  if (tile < tiles) {
+    old = combine_operand(tile);
+    load_half(tile, 1, rh);
+  }
   while (tile < tiles) {
     stage_half(1, rh);
+    const uint32_t old_now = old;
     const bool have_low = with_low;
     if (have_low) stage_half(0, rl);
     const int64_t next = tile + stride;
@@ -1381,6 +1407,7 @@ __device__ __forceinline__ void fle_pred32_early_body(const uint64_t* __restrict
     const uint32_t open_rows = (PAIR ? (hi.eq | hi2.eq) : hi.eq) & live;
     const bool undecided = __builtin_amdgcn_ballot_w64(open_rows != 0u) != 0ull;
     if (next < tiles) {  // prefetch: the high half always, the low half while the column needs it
+      old = combine_operand(next);
       load_half(next, 1, rh);
       if (undecided) load_half(next, 0, rl);
     }
@@ -1403,10 +1430,10 @@ __device__ __forceinline__ void fle_pred32_early_body(const uint64_t* __restrict
     uint32_t bm = finish_bitmap_dword(sel, tile, lane, n_rows);
     const int64_t d = tile * 64 + lane;
     if constexpr (PAGED) {
-      window_emit(*win, carry, d, bm, args.combine);
+      window_emit(*win, carry, d, bm, args.combine, kWave - 1, window_has_operand(*win, args.combine) ? &old_now : nullptr);
     } else if (d < bm_dwords) {
-      if (args.combine == 1) bm &= bitmap32[d];
-      else if (args.combine == 2) bm |= bitmap32[d];
+      if (args.combine == 1) bm &= old_now;
+      else if (args.combine == 2) bm |= old_now;
       IPS_BITMAP_STORE(bitmap32 + d, bm);
     }
     wave_lds_fence();  // LDS region is reused by the next sub-tile

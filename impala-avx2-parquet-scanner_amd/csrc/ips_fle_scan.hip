@@ -130,7 +130,9 @@ static ips_status launch_pred_wk(const uint64_t* enc, int64_t n_rows, const Pred
                                  uint32_t* bitmap32, hipStream_t s) {
   auto kern = fle_pred_w_kernel<W, KIND>;
   const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
-  int grid = grid_for_tiles(reinterpret_cast<const void*>(kern), tiles);
+  // (w <= 4: a sub-tile is 1 KiB, shares of one sub-tile per wave cost more in dispatches than they even out:
+  // 29 us at 8x, 33 us at 16x and beyond; from w = 6 on 32x is 3-7 % faster than 8x)
+  int grid = grid_for_tiles(reinterpret_cast<const void*>(kern), tiles, W >= 6 ? kGridPred : kGridScan);
   if (grid <= 0) return IPS_ERR_HIP;
   hipLaunchKernelGGL(kern, dim3(grid + args.aux_blocks), dim3(kThreads), 0, s, enc, n_rows, args, bitmap32);
   IPS_HIP_TRY(hipGetLastError());

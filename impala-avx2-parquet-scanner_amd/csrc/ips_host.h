@@ -63,9 +63,10 @@ ips_status hip_fail(hipError_t e, const char* what);
 
 // Blocks to launch for a grid-stride kernel over 'tiles' wave sub-tiles: enough to fill every CU
 // at the kernel's occupancy, never more than the work.  Occupancy is queried once per kernel.
-int grid_for_tiles(const void* kernel, int64_t tiles);
+enum GridKind { kGridScan = 0, kGridPred = 1, kGridChain = 2 };  // grid_mult
+int grid_for_tiles(const void* kernel, int64_t tiles, int kind = kGridScan);
 int device_cus();
-int grid_mult();
+int grid_mult(int kind = kGridScan);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -16,7 +16,7 @@
     defined(IPS_GATHER_WIDE) || defined(IPS_GATHER_MAX_4) || defined(IPS_QUADS) || defined(IPS_QUADS16) || \
     defined(IPS_PHASE_B_GROUP) || defined(IPS_NT_VALUE_STORE) || defined(IPS_DECODE_PACKED) ||          \
     defined(IPS_EXP_ROUNDS) || defined(IPS_AUX_NT) || defined(IPS_PLAIN_ABLATE) || defined(IPS_MIN_SHARE) || defined(IPS_PLAIN_DENSE8) ||  \
-    defined(IPS_WINDOW_ABLATE)
+    defined(IPS_WINDOW_ABLATE) || defined(IPS_GRID_MULT_PRED) || defined(IPS_GRID_MULT_CHAIN)
 #error "development switches need -DIPS_DEV_KNOBS (the default library has none)"
 #endif
 #endif
@@ -85,13 +85,22 @@
 #endif
 // IPS_WINDOW_ABLATE: defined = shared bitmap dwords are not merged (timing only, RESULTS ARE WRONG)
 
+// ---- grid sizes (ips_capi.hip: grid_mult) ----------------------------------------------------
+#ifndef IPS_GRID_MULT_PRED
+#define IPS_GRID_MULT_PRED 32       // workgroups per resident slot: stand-alone FLE predicate kernels of w >= 6 (w = 12: 71 -> 67 us)
+#endif
+#ifndef IPS_GRID_MULT_CHAIN
+#define IPS_GRID_MULT_CHAIN 64      // ... the one-pass conjunct chain (Q6 shape: 8x 297 us, 16x 289, 32x 284, 64x = one stripe per wave 279)
+#endif
+
 // ---- rank tiles (ips_rank_device.h) ----------------------------------------------------------
 #ifndef IPS_EXP_ROUNDS
 #define IPS_EXP_ROUNDS 2            // 16-byte root loads per lane of an expand / leaf workgroup
 #endif
 
 // ---- run-time switches of -DIPS_DEV_KNOBS builds ---------------------------------------------
-// IPS_GRID_MULT=<k>            blocks launched per resident block slot (default 8)
+// IPS_GRID_MULT=<k>            blocks launched per resident block slot (default 8); IPS_GRID_MULT_PRED / _CHAIN: the
+//                              predicate-only kernels / the one-pass chain
 // IPS_IN_TABLE_MIN=<K>         IN lists of >= K constants take the membership table, every width
 // IPS_NO_EARLY_PRUNE=1         w = 32 comparisons without the high-planes-first pruning
 // IPS_NO_FUSED_LEAF=1          nullable leaf as predicate + expand launches

@@ -268,13 +268,28 @@ __device__ __forceinline__ void plain_tile_body(const S* __restrict__ page, int6
     batch_step = sh.step;
     tiles_end = sh.end * G::TPB < n_tiles ? sh.end * G::TPB : n_tiles;
   }
+  // the dword an AND-into / OR-into launch combines with is prefetched with its tile (fle_pred_body)
+  auto combine_operand = [&](int64_t t) -> uint32_t {
+    const int64_t d = G::R == 32 ? t * 64 + lane : t * 32 + (lane >> 1);
+    if constexpr (GIVEN) return 0u;
+    if constexpr (PAGED) return (G::R == 32 && window_has_operand(*win, lit.combine)) ? window_operand(*win, d) : 0u;
+    return (lit.combine != 0 && (G::R == 32 || (lane & 1) == 0) && d < bm_dwords) ? bitmap32[d] : 0u;
+  };
   u32x4 r[kPlainLoads];
-  if (tile < tiles_end) plain_tile_load<S>(page, tile, n_rows, lane, r);
+  uint32_t old = 0u;
+  if (tile < tiles_end) {
+    old = combine_operand(tile);
+    plain_tile_load<S>(page, tile, n_rows, lane, r);
+  }
   uint32_t base = 0;  // rows of the batch selected in its earlier tile (8-byte slots)
   while (tile < tiles_end) {
     plain_tile_stage(lds, lane, r);
     const int64_t next = plain_next_tile<S>(tile, batch_step);
-    if (next < tiles_end) plain_tile_load<S>(page, next, n_rows, lane, r);  // register prefetch
+    const uint32_t old_now = old;
+    if (next < tiles_end) {  // register prefetch
+      old = combine_operand(next);
+      plain_tile_load<S>(page, next, n_rows, lane, r);
+    }
     wave_lds_fence();
 
     uint32_t m;
@@ -301,14 +316,14 @@ __device__ __forceinline__ void plain_tile_body(const S* __restrict__ page, int6
       (void)bm;
     } else if constexpr (PAGED) {
       if (G::R == 32) {
-        window_emit(*win, carry, d, bm, lit.combine);
+        window_emit(*win, carry, d, bm, lit.combine, kWave - 1, window_has_operand(*win, lit.combine) ? &old_now : nullptr);
       } else {  // dword k of the tile sits in lane 2k: bring it to lane k, 32 dwords per tile
         const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_bpermute((2 * lane) << 2, (int)bm);
         window_emit(*win, carry, tile * 32 + lane, mine, lit.combine, 31);
       }
     } else if ((G::R == 32 || (lane & 1) == 0) && d < bm_dwords) {
-      if (lit.combine == 1) bm &= bitmap32[d];
-      else if (lit.combine == 2) bm |= bitmap32[d];
+      if (lit.combine == 1) bm &= old_now;
+      else if (lit.combine == 2) bm |= old_now;
       IPS_BITMAP_STORE(bitmap32 + d, bm);
     }
     if (SCAN) {
@@ -409,7 +424,7 @@ static ips_status launch_plain_tiles(const void* page, int64_t n_rows, int op, c
   for (int i = 0; i < 16; ++i) lit.v[i] = i < n_literals ? reinterpret_cast<const T*>(literals)[i] : T();
   auto kern = plain_tile_kernel<T, S, SCAN>;
   const int64_t n_batches = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
-  const int grid = grid_for_tiles(reinterpret_cast<const void*>(kern), n_batches);  // a wave per batch
+  const int grid = grid_for_tiles(reinterpret_cast<const void*>(kern), n_batches);  // a wave per batch (predicate only: 4x..64x measure alike)
   if (grid <= 0) return IPS_ERR_HIP;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, s, reinterpret_cast<const S*>(page), n_rows, op, lit,
                      reinterpret_cast<uint32_t*>(bitmap), reinterpret_cast<S*>(batch_values), batch_counts);

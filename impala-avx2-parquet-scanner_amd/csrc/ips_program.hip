@@ -15,6 +15,7 @@
 #include <atomic>
 
 #include "ips_chunk_host.h"
+#include "ips_chain.h"
 
 namespace ips {
 
@@ -352,183 +353,6 @@ __global__ __launch_bounds__(kThreads) void program_kernel(Program prog, int64_t
     if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, top);
   }
 #endif
-}
-
-// ---------------------------------------------------------------------------------------------
-// Conjunct chain in ONE pass (EvalSimplePredicates' conjunct list, hdfs-parquet-scanner.cc:1857-
-// 1862, and any left-deep AND/OR chain of operands): up to kChainMaxOps operands, each a single
-// comparison / IN or a pair on one REQUIRED FLE column, evaluated column after column on the same
-// 2048-row sub-tile and combined in a register; every column is read once and the bitmap is written
-// once -- no read-modify-write of the bitmap per operand as in the per-operand plan (Q6 shape:
-// 1.73 GB moved instead of 2.03 GB).  The predicates stream the planes from LDS at one
-// v_bitop3_b32 per plane and comparison, so the run-time width costs nothing but the loop; the
-// operand descriptors are kernel arguments (scalar loads), the next operand's bytes are in flight
-// while the current one is evaluated.
-// ---------------------------------------------------------------------------------------------
-constexpr int kChainMaxOps = 4;
-constexpr int kChainMaxSlots = 16;  // 16-byte loads per lane and stripe
-struct ChainOp {
-  const uint64_t* enc;
-  int32_t w;
-  uint32_t inv_w;    // floor(2^32 / w) + 1
-  int32_t op1, join, op2, combine;  // combine: 0 first operand, 1 AND, 2 OR
-  uint32_t c1, c2;
-  int32_t n_in;      // > 0: op1 is IN over in_consts[0..n_in)
-  int32_t img_dw;    // dword offset of this operand's plane image in the wave's LDS region
-  uint32_t in_consts[16];
-};
-template <int N>
-struct ChainArgs {
-  ChainOp ops[N];
-  // load slot i of a stripe: chunks [slot_first[i], slot_first[i] + 64) of operand slot_op[i]
-  int32_t slot_op[kChainMaxSlots];
-  int32_t slot_first[kChainMaxSlots];
-};
-
-// The sub-tiles of all operands for the same 2048 rows form one STRIPE; its 16-byte chunks are
-// dealt to LOAD SLOTS of 64 chunks, every slot inside one operand (w = 12: three slots, w = 4:
-// one, w = 6: two), so that everything about a slot is wave-uniform -- the operand's buffer
-// resource, width and LDS image -- and the whole next stripe (5.5 KB on the Q6 shape) is in flight
-// per wave while the current one is evaluated, in LTOT x 4 registers: 74 VGPRs, 6 waves per SIMD.
-// Measured on the Q6 shape (600 M rows, w = 12 / 4 / 6): 318-343 us against 337-345 us for the
-// three per-operand launches, i.e. still a tie although it moves 15 % fewer bytes -- SQ counters:
-// 519 SALU + 51 SMEM against 177 VALU per stripe (the three stand-alone kernels together: 158 / 5 /
-// 116).  With widths and operators known only at run time the constants' plane masks (2-3 scalar
-// ops per plane and constant), the operator decoding, the slots' buffer resources and the operand
-// descriptors are all re-derived per stripe on the CU's one scalar unit, which runs at 0.72
-// instructions per cycle.  Hoisting the slot state into scalar registers spilled 126 of them
-// (385 us); lane-owned chunks across operand boundaries with per-lane pointers took 130 VGPRs
-// (430-500 us); one operand's piece in flight at a time: 344 us.  The kernel stays opt-in
-// (ips_set_program_strategy(IPS_PROGRAM_ONE_PASS)); closing the gap needs the widths at compile time.
-template <int N, int LTOT>
-__global__ __launch_bounds__(kThreads, LTOT <= 8 ? 6 : IPS_MIN_WAVES_PER_EU) void fle_chain_kernel(
-    ChainArgs<N> a, int64_t n_rows, uint32_t* __restrict__ bitmap32, int image_dwords, int n_slots) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
-  const int lane = lane_id();
-  const int wave = wave_id();
-  uint32_t* lds32 = lds_all + wave * image_dwords;
-  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
-  const int64_t n_blocks = (n_rows + 63) / 64;
-  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
-  const int64_t bm_dwords = bitmap_dwords(n_rows);
-  int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-
-  u32x4 r[LTOT];
-  auto load = [&](int64_t t) {
-#pragma unroll
-    for (int i = 0; i < LTOT; ++i) {
-      if (i < n_slots) {  // wave-uniform
-        const ChainOp& o = a.ops[a.slot_op[i]];
-        // chunks past the operand's 16 w, and words past the column, are out of the resource's range: zeros
-        const __amdgpu_buffer_rsrc_t rsrc = tile_rsrc(o.enc, t, o.w, n_blocks * o.w);
-        r[i] = buffer_load16<true>(rsrc, (uint32_t)(a.slot_first[i] + lane) * 16u);
-      }
-    }
-  };
-  if (tile < tiles) load(tile);
-  while (tile < tiles) {
-    const int64_t next = tile + stride;
-#pragma unroll
-    for (int i = 0; i < LTOT; ++i) {
-      if (i < n_slots) {
-        const ChainOp& o = a.ops[a.slot_op[i]];
-        const int c = a.slot_first[i] + lane;
-        if (c < 16 * o.w) {
-          // (odd w: block stride w, the image is linear; even w: both words belong to one block)
-          const int wi = 2 * c;
-          const int blk = (int)__umulhi((uint32_t)wi, o.inv_w);
-          uint32_t* dst = lds32 + o.img_dw + 2 * (blk * (o.w | 1) + (wi - blk * o.w));
-          const u32x2 lo = {r[i].x, r[i].y}, hi = {r[i].z, r[i].w};
-          *reinterpret_cast<u32x2*>(dst) = lo;
-          *reinterpret_cast<u32x2*>(dst + 2) = hi;
-        }
-      }
-    }
-    if (next < tiles) load(next);  // register prefetch of the whole next stripe
-    wave_lds_fence();
-    uint32_t acc = 0u;
-#pragma unroll 1  // the descriptor of an operand is read from the kernel arguments when its turn comes
-    for (int i = 0; i < N; ++i) {
-      const ChainOp& o = a.ops[i];
-      const uint32_t* img = lds32 + o.img_dw;
-      uint32_t sel;
-      if (o.n_in > 0) {
-        sel = pred_in_from_lds(img, o.w, lane, o.in_consts, o.n_in);
-      } else if (o.join != 0) {
-        uint32_t r1, r2;
-        pred_pair_from_lds(img, o.w, lane, o.op1, o.c1, o.op2, o.c2, &r1, &r2);
-        sel = o.join == 1 ? (r1 & r2) : (r1 | r2);
-      } else {
-        sel = pred_single_from_lds(img, o.w, lane, o.op1, o.c1);
-      }
-      acc = i == 0 ? sel : (o.combine == 1 ? (acc & sel) : (acc | sel));
-    }
-    const uint32_t bm = finish_bitmap_dword(acc, tile, lane, n_rows);
-    const int64_t d = tile * 64 + lane;
-    if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, bm);
-    wave_lds_fence();  // the images are rewritten by the next stripe
-    tile = next;
-  }
-}
-
-template <int N, int LTOT>
-static ips_status launch_chain_nl(const ChainArgs<N>& a, int image_dwords, int n_slots, int64_t n_rows,
-                                  uint32_t* bitmap32, hipStream_t s) {
-  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
-  auto kern = fle_chain_kernel<N, LTOT>;
-  const size_t lds = (size_t)kWavesPerBlock * image_dwords * 4;
-  // resident size: the dynamic image is not known to the occupancy cache of grid_for_tiles
-  static std::mutex mu;
-  static std::map<size_t, int> resident;  // per instantiation: image bytes -> workgroups per CU
-  int per_cu = 0;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = resident.find(lds);
-    if (it != resident.end()) per_cu = it->second;
-  }
-  if (per_cu == 0) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kThreads, lds) != hipSuccess || per_cu <= 0)
-      per_cu = 2;
-    std::lock_guard<std::mutex> lk(mu);
-    resident[lds] = per_cu;
-  }
-  const int64_t want = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int64_t cap = (int64_t)device_cus() * per_cu * grid_mult();
-  const int64_t rounds = (want + cap - 1) / cap;
-  const int grid = (int)(want <= cap ? want : (want + rounds - 1) / rounds);
-  if (grid <= 0) return IPS_ERR_HIP;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, a, n_rows, bitmap32, image_dwords, n_slots);
-  IPS_HIP_TRY(hipGetLastError());
-  return IPS_OK;
-}
-
-// load slots of a chain: 64 chunks each, never across operands
-static int chain_slots(const int* widths, int n) {
-  int slots = 0;
-  for (int i = 0; i < n; ++i) slots += (16 * widths[i] + kWave - 1) / kWave;
-  return slots;
-}
-
-// ops[i].inv_w / img_dw and the slot table are filled here; chain_slots(...) <= kChainMaxSlots
-template <int N>
-static ips_status launch_chain_n(const ChainOp* ops, int64_t n_rows, uint32_t* bitmap32, hipStream_t s) {
-  ChainArgs<N> a;
-  memset(&a, 0, sizeof(a));
-  int slots = 0, img = 0;
-  for (int i = 0; i < N; ++i) {
-    a.ops[i] = ops[i];
-    a.ops[i].inv_w = (uint32_t)(0x100000000ull / (uint64_t)ops[i].w) + 1u;
-    a.ops[i].img_dw = img;
-    img += plane_tile_bytes(ops[i].w) / 4;
-    for (int c = 0; c < 16 * ops[i].w; c += kWave) {
-      a.slot_op[slots] = i;
-      a.slot_first[slots] = c;
-      ++slots;
-    }
-  }
-  if (slots <= 4) return launch_chain_nl<N, 4>(a, img, slots, n_rows, bitmap32, s);
-  if (slots <= 8) return launch_chain_nl<N, 8>(a, img, slots, n_rows, bitmap32, s);
-  return launch_chain_nl<N, 16>(a, img, slots, n_rows, bitmap32, s);
 }
 
 ips_status launch_program(const Program& prog, int64_t n_rows, uint32_t* bitmap32, hipStream_t s) {
@@ -921,46 +745,48 @@ extern "C" ips_status ips_eval_program(const ips_node* nodes, int n_nodes, const
   if (strategy != IPS_PROGRAM_ONE_LAUNCH) {
     Plan pl;
     if (make_plan(nodes, n_nodes, &pl)) {
-      // a pure chain over REQUIRED FLE columns can run as one pass with one bitmap write
-      // (IPS_PROGRAM_ONE_PASS).  Not what AUTO picks: with run-time widths it is bound by the scalar
-      // unit and only ties the three per-operand launches on the Q6 shape (see fle_chain_kernel).
-      if (pl.n_slots == 1 && !any_nullable && pl.n_steps >= 2 && pl.n_steps <= kChainMaxOps &&
-          strategy == IPS_PROGRAM_ONE_PASS) {
-        ChainOp ops[kChainMaxOps];
+      // a pure chain over REQUIRED FLE columns runs as one pass with one bitmap write (ips_chain.hip):
+      // what AUTO picks, and what IPS_PROGRAM_ONE_PASS asks for; IPS_PROGRAM_PER_OPERAND keeps the launches
+      if (pl.n_slots == 1 && !any_nullable && pl.n_steps >= 2 && pl.n_steps <= kChainWMaxOps &&
+          (strategy == IPS_PROGRAM_ONE_PASS || strategy == IPS_PROGRAM_AUTO)) {
+        ChainArgsW ca;
+        memset(&ca, 0, sizeof(ca));
+        const void* enc[kChainWMaxOps];
         bool ok = true;
-        int widths[kChainMaxOps];
         for (int i = 0; i < pl.n_steps && ok; ++i) {
           const Step& p = pl.steps[i];
           const ips_node* la = p.item.a;
           const ips_node* lb = p.item.b;
           const ips_column& c = cols[la->column];
           ok = p.kind == 0 && c.encoding == IPS_COL_FLE && (i == 0 ? p.combine == 0 : p.combine != 0) && !la->inset;
+          // AUTO leaves 32-bit comparisons to their stand-alone kernel, which reads the low planes only of
+          // the sub-tiles the high planes leave undecided ((32, 8): 153 us per operand, 233 us in one pass)
+          if (strategy == IPS_PROGRAM_AUTO && c.bit_width == 32 && la->op != IPS_OP_IN) ok = false;
           if (!ok) break;
-          widths[i] = c.bit_width;
-          memset(&ops[i], 0, sizeof(ChainOp));
-          ops[i].enc = reinterpret_cast<const uint64_t*>(c.d_data);
-          ops[i].w = c.bit_width;
-          ops[i].op1 = la->op;
-          ops[i].c1 = (uint32_t)la->consts[0];
-          ops[i].combine = p.combine;
+          ChainOpW& o = ca.ops[i];
+          enc[i] = c.d_data;
+          o.w = c.bit_width;
+          o.op = la->op;
+          o.c1 = (uint32_t)la->consts[0];
+          o.combine = p.combine;
           if (la->op == IPS_OP_IN) {
-            ops[i].n_in = la->n_consts;
-            for (int j = 0; j < la->n_consts; ++j) ops[i].in_consts[j] = (uint32_t)la->consts[j];
-          }
-          if (lb) {
-            ops[i].join = p.item.join;
-            ops[i].op2 = lb->op;
-            ops[i].c2 = (uint32_t)lb->consts[0];
+            o.kind = kChainIn;
+            o.n_in = la->n_consts;
+            for (int j = 0; j < la->n_consts; ++j) o.in_consts[j] = (uint32_t)la->consts[j];
+          } else if (lb) {
+            o.kind = kChainPair;
+            o.join = p.item.join;
+            o.op2 = lb->op;
+            o.c2 = (uint32_t)lb->consts[0];
+          } else {
+            o.kind = kChainSingle;
           }
         }
-        if (ok && chain_slots(widths, pl.n_steps) <= kChainMaxSlots) {
-          uint32_t* bm32 = reinterpret_cast<uint32_t*>(d_bitmap);
-          hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
-          switch (pl.n_steps) {
-            case 2: return launch_chain_n<2>(ops, n_rows, bm32, hs);
-            case 3: return launch_chain_n<3>(ops, n_rows, bm32, hs);
-            default: return launch_chain_n<4>(ops, n_rows, bm32, hs);
-          }
+        if (ok) {
+          ca.n_ops = pl.n_steps;
+          const ips_status st = launch_chain_w(ca, enc, n_rows, reinterpret_cast<uint32_t*>(d_bitmap),
+                                               reinterpret_cast<hipStream_t>(stream));
+          if (st != IPS_ERR_UNSUPPORTED) return st;  // (too many load slots, a column of 4 GiB: the plan below)
         }
       }
       IPS_REQUIRE((pl.n_slots <= 1 && !any_nullable) || (d_workspace && aligned16(d_workspace)),

@@ -430,13 +430,16 @@ typedef struct {
                             (ips_inset_open); n_consts / consts are then ignored.  NULL otherwise */
 } ips_node;
 
-/* How ips_eval_program evaluates a tree.  AUTO (the default) = PER_OPERAND: one launch of a
- * stand-alone predicate kernel per operand (a leaf, or two leaves on one column such as BETWEEN, in
- * one pass) writing / AND-ing / OR-ing into a bitmap -- those kernels run at 70-80 % of the HBM
- * roofline.  ONE_PASS: a conjunct / disjunct chain of up to four operands on REQUIRED FLE columns as
- * one kernel that writes the bitmap once (other trees fall back to PER_OPERAND).  ONE_LAUNCH: the
- * whole tree as one stack-machine kernel (REQUIRED columns only; 2-3x slower, for callers that
- * must have a single launch).  Process-wide; every strategy produces identical bitmaps. */
+/* How ips_eval_program evaluates a tree.  PER_OPERAND: one launch of a stand-alone predicate kernel
+ * per operand (a leaf, or two leaves on one column such as BETWEEN, in one pass) writing / AND-ing /
+ * OR-ing into a bitmap -- those kernels run at 70-80 % of the HBM roofline.  ONE_PASS: a left-deep
+ * conjunct / disjunct chain of two to six operands on REQUIRED FLE columns (comparisons, pairs, IN
+ * lists of up to 16 constants; at most 16 KiB of planes per 2048 rows) as ONE kernel that reads every
+ * column once and writes the bitmap once; other trees fall back to PER_OPERAND.  AUTO (the default):
+ * ONE_PASS for such chains unless one of them compares a 32-bit column (its stand-alone kernel skips
+ * the low planes of decided sub-tiles), PER_OPERAND otherwise.  ONE_LAUNCH: the whole tree as one
+ * stack-machine kernel (REQUIRED columns only; 2-3x slower, for callers that must have a single
+ * launch).  Process-wide; every strategy produces identical bitmaps. */
 typedef enum { IPS_PROGRAM_AUTO = 0, IPS_PROGRAM_PER_OPERAND = 1, IPS_PROGRAM_ONE_PASS = 2,
                IPS_PROGRAM_ONE_LAUNCH = 3 } ips_program_strategy;
 ips_status ips_set_program_strategy(int strategy);

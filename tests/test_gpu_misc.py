@@ -824,3 +824,72 @@ def test_in_sets_of_any_length(capi, O):
     empty = capi.InSet(np.zeros(0, np.uint64))
     assert int(capi.fle_pred_inset(enc, n, 16, empty).abs().sum().item()) == 0
     empty.close()
+
+
+@pytest.mark.gpu
+def test_one_pass_conjunct_chain(capi, O, request):
+    """ips_set_program_strategy(ONE_PASS): left-deep AND / OR chains of 2..6 operands over REQUIRED FLE
+    columns of every width -- single comparisons, pairs on one column (BETWEEN and its OR twin), IN lists --
+    run as ONE launch whose per-operand code is selected by a switch on the width (ips_chain.hip).  Checked
+    against numpy on the raw codes and against the per-operand plan, row counts around the 2048-row sub-tile."""
+    request.addfinalizer(lambda: capi.set_program_strategy(capi.PROGRAM_AUTO))
+    rng = np.random.default_rng(77)
+    L, AND, OR = capi.leaf, capi.and_node, capi.or_node
+    cmp_np = {O.OP_EQ: np.equal, O.OP_LT: np.less, O.OP_LE: np.less_equal, O.OP_GT: np.greater, O.OP_GE: np.greater_equal}
+    widths_seen = set()
+    for trial in range(40):
+        n = int(rng.choice([1, 63, 2047, 2048, 2049, 6145, 40961, 100003]))
+        n_ops = int(rng.integers(2, 7))
+        # the first trials walk through every width once
+        widths = [int(rng.integers(1, 33)) for _ in range(n_ops)]
+        if trial < 16:
+            widths[0] = 2 * trial + 1
+            widths[1] = 2 * trial + 2
+        widths_seen.update(widths)
+        cols, raw, nodes, keep = [], [], [], []
+        exp = None
+        for i, w in enumerate(widths):
+            hi = (1 << w) - 1
+            # a narrow value range now and then so that EQ / IN select something on wide columns
+            span = hi if rng.random() < 0.6 else min(hi, 15)
+            v = rng.integers(0, span + 1, n, dtype=np.uint64).astype(np.uint32)
+            raw.append(v)
+            keep.append(dev_words(O.fle_encode(v, w)))  # (the column descriptor only holds the address)
+            cols.append(capi.fle_column(keep[-1], w))
+            kind = rng.integers(0, 3)
+            if kind == 0:
+                op = int(rng.integers(0, 5))
+                c = int(rng.integers(0, span + 1))
+                nodes.append(L(i, op, c))
+                sel = cmp_np[op](v, np.uint32(c))
+            elif kind == 1:
+                op1, op2 = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+                c1, c2 = int(rng.integers(0, span + 1)), int(rng.integers(0, span + 1))
+                nodes += [L(i, op1, c1), L(i, op2, c2)]
+                s1, s2 = cmp_np[op1](v, np.uint32(c1)), cmp_np[op2](v, np.uint32(c2))
+                if rng.random() < 0.7:
+                    nodes.append(AND())
+                    sel = s1 & s2
+                else:
+                    nodes.append(OR())
+                    sel = s1 | s2
+            else:
+                k = int(rng.integers(1, 17))
+                members = [int(x) for x in rng.integers(0, span + 1, k)]
+                nodes.append(L(i, O.OP_IN, members))
+                sel = np.isin(v, np.array(members, dtype=np.uint32))
+            if i == 0:
+                exp = sel
+            elif rng.random() < 0.75:
+                nodes.append(AND())
+                exp = exp & sel
+            else:
+                nodes.append(OR())
+                exp = exp | sel
+        capi.set_program_strategy(capi.PROGRAM_ONE_PASS)
+        got = bits_of(words(capi.eval_program(nodes, cols, n)), n)
+        assert np.array_equal(got, exp), (trial, n, widths)
+        capi.set_program_strategy(capi.PROGRAM_PER_OPERAND)
+        ref = bits_of(words(capi.eval_program(nodes, cols, n)), n)
+        assert np.array_equal(ref, exp), (trial, n, widths)
+    assert widths_seen == set(range(1, 33))
