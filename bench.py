@@ -310,14 +310,19 @@ def leg_page_lists(ips, capi, dev):
     t_c, _ = time_launches(lambda: capi.eval_program(nodes, cols, n, bitmap=ref))
     del encs, cols
     bm = torch.empty_like(ref)
-    for label, sizes in (("573 pages of 2^20 rows per column", (1 << 20,) * 3),
-                         ("pages of 2^20 / 2^20 - 37 / 700,001 rows (page ends differ between the columns)",
-                          (1 << 20, (1 << 20) - 37, 700001))):
+    # pages that hold the same rows in every column: the one-pass chain, blockIdx.y = page (1 launch; with
+    # page starts inside bitmap dwords + 1 fix-up launch); page ends that differ between the columns: 3
+    # per-operand launches + their fix-ups
+    for label, sizes, launches in (("573 pages of 2^20 rows per column", (1 << 20,) * 3, 1),
+                                   ("573 pages of 2^20 - 37 rows per column (every page starts inside a bitmap dword)",
+                                    ((1 << 20) - 37,) * 3, 2),
+                                   ("pages of 2^20 / 2^20 - 37 / 700,001 rows (page ends differ between the columns)",
+                                    (1 << 20, (1 << 20) - 37, 700001), 5)):
         chunks = [chunk_of(codes[c], q6.COLUMNS[c][3], sizes[c]) for c in range(3)]
         tmed, tmin = time_launches(lambda: capi.eval_program_chunks(nodes, chunks, bitmap=bm))
         out.append(rec(f"configs[4] Q6 conjunction over page lists, {label}", n, q6.algorithmic_bytes(n), tmed, tmin,
                        bool(torch.equal(bm, ref)), vs_contiguous=round(tmed / t_c, 3),
-                       launches_per_step=3))
+                       launches_per_step=launches))
         for ch in chunks:
             ch.close()
         del chunks
@@ -827,7 +832,7 @@ def leg_q6_sharded(ips, capi, dev, dist, comm, comm_stream, world, rank):
             "rows_per_s": round(n / t, 1), "algorithmic_bytes": q6.algorithmic_bytes(n),
             "GBps_aggregate": round(q6.algorithmic_bytes(n) / t / 1e9, 1), "scaling": "strong",
             "check": bool(okt.item()),
-            "launches_per_step": "3 predicate launches over all pieces (ips_eval_program_chunks_allgather) + one "
+            "launches_per_step": "one one-pass chain launch over all pieces (ips_eval_program_chunks_allgather) + one "
                                  "waiter and one ncclAllGather per piece on the communicator's stream",
             "check_detail": "each rank's gathered pieces vs torch on the raw codes; all ranks hold identical words"}
 

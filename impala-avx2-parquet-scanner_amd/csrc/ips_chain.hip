@@ -20,12 +20,13 @@
 // Round 2's kernel (fle_chain_kernel) evaluated with run-time widths and re-derived resources per
 // slot: 519 scalar instructions per stripe, a tie with the three launches.
 #include "ips_device.h"
-#include "ips_host.h"
+#include "ips_chunk_host.h"
 #include "ips_chain.h"
 
 #include <map>
 #include <mutex>
 #include <type_traits>
+#include <utility>
 
 namespace ips {
 
@@ -143,34 +144,62 @@ constexpr int chain_min_waves(int ltot, int maxw) {
   return maxw <= 16 ? (ltot <= 4 ? 8 : ltot <= 6 ? 5 : ltot <= 8 ? 4 : 3) : (ltot <= 8 ? 4 : 3);
 }
 
-// (the kernel's first parameter is read through the kernarg segment pointer: it sits at offset 0)
-template <int LTOT, int MAXW>
-__global__ __launch_bounds__(kThreads, chain_min_waves(LTOT, MAXW)) void fle_chain_w_kernel(
-    ChainArgsW a_by_value, int64_t n_rows, uint32_t* __restrict__ bitmap32) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
-  (void)a_by_value;
-  const ChainArgsK a = (ChainArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+typedef const ChainPagedArgsW __attribute__((address_space(4))) * ChainPagedArgsK;
+
+// a buffer resource whose four words the host prepared (no scalar ops in the kernel)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t host_rsrc(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+  const u32x4 words = {w0, w1, w2, w3};
+  __amdgpu_buffer_rsrc_t rsrc;
+  __builtin_memcpy(&rsrc, &words, 16);
+  return rsrc;
+}
+
+// PAGED: blockIdx.y = page; the page's rows in every operand's own block geometry (FLE blocks restart at
+// the page's first row, which is the same row in every operand's chunk), the stripe's bitmap dwords through
+// the page's window into the chunk-wide bitmap.
+template <int LTOT, int MAXW, bool PAGED>
+__device__ __forceinline__ void chain_body(ChainArgsK a, ChainPagedArgsK pa, int64_t n_rows, uint32_t* __restrict__ bitmap32,
+                                           uint32_t* lds_all) {
   const int lane = lane_id();
   const int wave = wave_id();
   uint32_t* lds32 = lds_all + wave * a->image_dwords;
-  const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
-  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  [[maybe_unused]] ChunkPage pg;
+  [[maybe_unused]] BitmapWindow win;
+  if constexpr (PAGED) {
+    pg = reinterpret_cast<const ChunkPage*>(pa->pg.pages[0])[blockIdx.y];
+    n_rows = pg.n_data;
+    win = bitmap_window(bitmap32, pg, pa->pg.chunk_rows, pa->pg.done, pa->pg.edges);
+  }
+  int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
   const int64_t bm_dwords = bitmap_dwords(n_rows);
   const int n_ops = a->n_ops;
   const uint32_t lane_byte = (uint32_t)lane * 16u;
   int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  [[maybe_unused]] WindowCarry carry;
+  if constexpr (PAGED) {
+    const TileShare sh = tile_share(win, tiles, tile, stride);
+    tile = sh.first;
+    stride = sh.step;
+    tiles = sh.end;
+  }
 
   u32x4 r[LTOT];
   // slot i of stripe t: chunks beyond the sub-tile's 16 w take an offset outside every column (zeros, no
   // traffic); bytes beyond the column's end are outside the resource
   auto load_slot = [&](int i, int64_t t) {
     const uint32_t first = a->slots[i].first_byte, tile_bytes = a->slots[i].tile_bytes;
-    const u32x4 words = {a->slots[i].rsrc[0], a->slots[i].rsrc[1], a->slots[i].rsrc[2], a->slots[i].rsrc[3]};
-    __amdgpu_buffer_rsrc_t rsrc;  // prepared by the host
-    __builtin_memcpy(&rsrc, &words, 16);
     const uint32_t in_tile = first + lane_byte;
     const uint32_t off = in_tile < tile_bytes ? (uint32_t)t * tile_bytes + in_tile : 0xFFFFFFF0u;
-    r[i] = buffer_load16<true>(rsrc, off);
+    if constexpr (PAGED) {  // over the page's bytes in this operand's chunk
+      const ChunkPage* pages = reinterpret_cast<const ChunkPage*>(pa->pg.pages[a->slots[i].rsrc[0]]);
+      const uint64_t* base = pages[blockIdx.y].data;
+      const int64_t bytes = ((n_rows + 63) / 64) * (int64_t)(tile_bytes >> 5);
+      r[i] = buffer_load16<true>(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(base), 0, tile_bytes ? (int)bytes : 0,
+                                                                   kBufferRsrcDword3), off);
+    } else {
+      r[i] = buffer_load16<true>(host_rsrc(a->slots[i].rsrc[0], a->slots[i].rsrc[1], a->slots[i].rsrc[2], a->slots[i].rsrc[3]), off);
+    }
   };
   auto stage_slot = [&](int i) {
     const uint32_t first = a->slots[i].first_byte, tile_bytes = a->slots[i].tile_bytes;
@@ -212,10 +241,54 @@ __global__ __launch_bounds__(kThreads, chain_min_waves(LTOT, MAXW)) void fle_cha
     }
     const uint32_t bm = finish_bitmap_dword(acc, tile, lane, n_rows);
     const int64_t d = tile * 64 + lane;
-    if (d < bm_dwords) IPS_BITMAP_STORE(bitmap32 + d, bm);
+    if constexpr (PAGED) {
+      window_emit(win, carry, d, bm, 0);
+    } else if (d < bm_dwords) {
+      IPS_BITMAP_STORE(bitmap32 + d, bm);
+    }
     wave_lds_fence();  // the images are rewritten by the next stripe
     tile = next;
   }
+  if constexpr (PAGED) {
+    window_flush(win, carry, 0);
+    page_done(pa->pg.done, pa->pg.done_page0, pa->pg.done_epoch);
+  }
+}
+
+// (the kernels' first parameter is read through the kernarg segment pointer: it sits at offset 0)
+template <int LTOT, int MAXW>
+__global__ __launch_bounds__(kThreads, chain_min_waves(LTOT, MAXW)) void fle_chain_w_kernel(
+    ChainArgsW a_by_value, int64_t n_rows, uint32_t* __restrict__ bitmap32) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
+  (void)a_by_value;
+  chain_body<LTOT, MAXW, false>((ChainArgsK)__builtin_amdgcn_kernarg_segment_ptr(), nullptr, n_rows, bitmap32, lds_all);
+}
+
+template <int LTOT, int MAXW>
+__global__ __launch_bounds__(kThreads, chain_min_waves(LTOT, MAXW)) void fle_chain_w_pages_kernel(
+    ChainPagedArgsW a_by_value, uint32_t* __restrict__ bitmap32) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
+  (void)a_by_value;
+  const ChainPagedArgsK pa = (ChainPagedArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+  chain_body<LTOT, MAXW, true>((ChainArgsK)pa, pa, 0, bitmap32, lds_all);
+}
+
+// resident workgroups per CU of a kernel with 'lds' bytes of dynamic image (not known to the occupancy cache
+// of grid_for_tiles)
+static int chain_resident(const void* kern, size_t lds) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, size_t>, int> resident;
+  const auto key = std::make_pair(kern, lds);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = resident.find(key);
+    if (it != resident.end()) return it->second;
+  }
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kThreads, lds) != hipSuccess || per_cu <= 0) per_cu = 2;
+  std::lock_guard<std::mutex> lk(mu);
+  resident[key] = per_cu;
+  return per_cu;
 }
 
 template <int LTOT, int MAXW>
@@ -223,21 +296,7 @@ static ips_status launch_chain_w_class(const ChainArgsW& a, int64_t n_rows, uint
   const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   auto kern = fle_chain_w_kernel<LTOT, MAXW>;
   const size_t lds = (size_t)kWavesPerBlock * a.image_dwords * 4;
-  // resident size: the dynamic image is not known to the occupancy cache of grid_for_tiles
-  static std::mutex mu;
-  static std::map<size_t, int> resident;  // per instantiation: image bytes -> workgroups per CU
-  int per_cu = 0;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = resident.find(lds);
-    if (it != resident.end()) per_cu = it->second;
-  }
-  if (per_cu == 0) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kThreads, lds) != hipSuccess || per_cu <= 0)
-      per_cu = 2;
-    std::lock_guard<std::mutex> lk(mu);
-    resident[lds] = per_cu;
-  }
+  const int per_cu = chain_resident(reinterpret_cast<const void*>(kern), lds);
   const int64_t want = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
   const int64_t cap = (int64_t)device_cus() * per_cu * grid_mult(kGridChain);
   const int64_t rounds = (want + cap - 1) / cap;
@@ -248,12 +307,31 @@ static ips_status launch_chain_w_class(const ChainArgsW& a, int64_t n_rows, uint
   return IPS_OK;
 }
 
-// a.ops[0..n_ops) filled by the caller (w, kind, operators, constants, combine); enc[i] = operand i's column
-ips_status launch_chain_w(ChainArgsW& a, const void* const* enc, int64_t n_rows, uint32_t* bitmap32, hipStream_t s) {
-  int slots = 0, img = 0;
-  const int64_t n_blocks = (n_rows + 63) / 64;
+template <int LTOT, int MAXW>
+static ips_status launch_chain_w_pages_class(const ChainPagedArgsW& pa, int n_pages, int64_t max_rows,
+                                             uint32_t* bitmap32, hipStream_t s) {
+  const int64_t tiles = (max_rows + kRowsPerTile - 1) / kRowsPerTile;  // of the largest page
+  auto kern = fle_chain_w_pages_kernel<LTOT, MAXW>;
+  const size_t lds = (size_t)kWavesPerBlock * pa.chain.image_dwords * 4;
+  const int per_cu = chain_resident(reinterpret_cast<const void*>(kern), lds);
+  // x: shares of one page's stripes, so that x * pages fills the device about grid_mult times
+  const int64_t total = (int64_t)device_cus() * per_cu * grid_mult(kGridChain);
+  int64_t gx = (total + n_pages - 1) / n_pages;
+  const int64_t gx_max = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  gx = gx > gx_max ? gx_max : gx;
+  gx = gx < 1 ? 1 : gx;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)n_pages), dim3(kThreads), lds, s, pa, bitmap32);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+// slots, images and plane masks of a chain; enc = NULL: paged (the slot carries its operand, the resource
+// is made per page)
+static ips_status chain_layout(ChainArgsW& a, const void* const* enc, int64_t n_blocks, int* max_w) {
+  int slots = 0, img = 0, maxw = 0;
   for (int i = 0; i < a.n_ops; ++i) {
     const int w = a.ops[i].w;
+    maxw = w > maxw ? w : maxw;
     const int64_t bytes = n_blocks * w * 8;
     if (bytes >= 0xFFFFFFF0ll) return IPS_ERR_UNSUPPORTED;
     a.ops[i].img_dw = img;
@@ -264,11 +342,15 @@ ips_status launch_chain_w(ChainArgsW& a, const void* const* enc, int64_t n_rows,
     for (int c = 0; c < 16 * w; c += kWave) {
       if (slots == kChainWMaxSlots) return IPS_ERR_UNSUPPORTED;
       ChainSlot& sl = a.slots[slots++];
-      const uint64_t base = reinterpret_cast<uint64_t>(enc[i]);
-      sl.rsrc[0] = (uint32_t)base;
-      sl.rsrc[1] = (uint32_t)(base >> 32) & 0xFFFFu;
-      sl.rsrc[2] = (uint32_t)bytes;
-      sl.rsrc[3] = kBufferRsrcDword3;
+      if (enc) {
+        const uint64_t base = reinterpret_cast<uint64_t>(enc[i]);
+        sl.rsrc[0] = (uint32_t)base;
+        sl.rsrc[1] = (uint32_t)(base >> 32) & 0xFFFFu;
+        sl.rsrc[2] = (uint32_t)bytes;
+        sl.rsrc[3] = kBufferRsrcDword3;
+      } else {
+        sl.rsrc[0] = (uint32_t)i;
+      }
       sl.first_byte = (uint32_t)c * 16u;
       sl.tile_bytes = 256u * (uint32_t)w;
       sl.inv_w = (uint32_t)(0x100000000ull / (uint64_t)w) + 1u;
@@ -279,16 +361,33 @@ ips_status launch_chain_w(ChainArgsW& a, const void* const* enc, int64_t n_rows,
   a.n_slots = slots;
   a.image_dwords = img;
   if ((size_t)kWavesPerBlock * img * 4 > 64 * 1024) return IPS_ERR_UNSUPPORTED;
+  *max_w = maxw;
+  return IPS_OK;
+}
+
+#define IPS_CHAIN_DISPATCH(FN, SLOTS, MAXW, ...)                                              \
+  do {                                                                                        \
+    if ((SLOTS) <= 2) return (MAXW) <= 16 ? FN<2, 16>(__VA_ARGS__) : FN<2, 32>(__VA_ARGS__);   \
+    if ((SLOTS) <= 4) return (MAXW) <= 16 ? FN<4, 16>(__VA_ARGS__) : FN<4, 32>(__VA_ARGS__);   \
+    if ((SLOTS) <= 6) return (MAXW) <= 16 ? FN<6, 16>(__VA_ARGS__) : FN<6, 32>(__VA_ARGS__);   \
+    if ((SLOTS) <= 8) return (MAXW) <= 16 ? FN<8, 16>(__VA_ARGS__) : FN<8, 32>(__VA_ARGS__);   \
+    if ((SLOTS) <= 12) return (MAXW) <= 16 ? FN<12, 16>(__VA_ARGS__) : FN<12, 32>(__VA_ARGS__); \
+    return (MAXW) <= 16 ? FN<16, 16>(__VA_ARGS__) : FN<16, 32>(__VA_ARGS__);                   \
+  } while (0)
+
+// a.ops[0..n_ops) filled by the caller (w, kind, operators, constants, combine); enc[i] = operand i's column
+ips_status launch_chain_w(ChainArgsW& a, const void* const* enc, int64_t n_rows, uint32_t* bitmap32, hipStream_t s) {
   int maxw = 0;
-  for (int i = 0; i < a.n_ops; ++i) maxw = a.ops[i].w > maxw ? a.ops[i].w : maxw;
-#define IPS_CHAIN_CLASS(L)                                                                  \
-  if (slots <= L)                                                                           \
-    return maxw <= 16 ? launch_chain_w_class<L, 16>(a, n_rows, bitmap32, s)                 \
-                      : launch_chain_w_class<L, 32>(a, n_rows, bitmap32, s);
-  IPS_CHAIN_CLASS(2) IPS_CHAIN_CLASS(4) IPS_CHAIN_CLASS(6) IPS_CHAIN_CLASS(8) IPS_CHAIN_CLASS(12)
-#undef IPS_CHAIN_CLASS
-  return maxw <= 16 ? launch_chain_w_class<16, 16>(a, n_rows, bitmap32, s)
-                    : launch_chain_w_class<16, 32>(a, n_rows, bitmap32, s);
+  const ips_status st = chain_layout(a, enc, (n_rows + 63) / 64, &maxw);
+  if (st != IPS_OK) return st;
+  IPS_CHAIN_DISPATCH(launch_chain_w_class, a.n_slots, maxw, a, n_rows, bitmap32, s);
+}
+
+ips_status launch_chain_w_pages(ChainPagedArgsW& pa, int n_pages, int64_t max_rows, uint32_t* bitmap32, hipStream_t s) {
+  int maxw = 0;
+  const ips_status st = chain_layout(pa.chain, nullptr, (max_rows + 63) / 64, &maxw);
+  if (st != IPS_OK) return st;
+  IPS_CHAIN_DISPATCH(launch_chain_w_pages_class, pa.chain.n_slots, maxw, pa, n_pages, max_rows, bitmap32, s);
 }
 
 }  // namespace ips

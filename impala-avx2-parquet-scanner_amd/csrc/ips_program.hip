@@ -956,6 +956,65 @@ ips_status eval_program_chunks_signalled(const ips_node* nodes, int n_nodes, con
     if (slot == pl.root) return d_bitmap;
     return reinterpret_cast<uint64_t*>(temp + slot_bytes * (size_t)(slot < pl.root ? slot : slot - 1));
   };
+  // A chain over REQUIRED FLE chunks whose pages hold the same rows in every chunk runs as ONE launch
+  // (ips_chain.hip: blockIdx.y = page); pages cut differently per column, OPTIONAL chunks, dictionary widths
+  // that grow inside a chunk and 32-bit comparisons (AUTO) take the per-operand launches below.
+  const int strategy = g_program_strategy.load(std::memory_order_relaxed);
+  if (pl.n_slots == 1 && pl.n_steps >= 2 && pl.n_steps <= kChainWMaxOps &&
+      (strategy == IPS_PROGRAM_AUTO || strategy == IPS_PROGRAM_ONE_PASS)) {
+    ChainPagedArgsW pa;
+    memset(&pa, 0, sizeof(pa));
+    bool ok = true;
+    const ips_chunk* c0 = chunks[pl.steps[0].item.a->column];
+    for (int i = 0; i < pl.n_steps && ok; ++i) {
+      const Step& p = pl.steps[i];
+      const ips_node* la = p.item.a;
+      const ips_node* lb = p.item.b;
+      const ips_chunk* c = chunks[la->column];
+      ok = p.kind == 0 && c->encoding == IPS_COL_FLE && c->max_def_level == 0 && c->runs.size() == 1 && !la->inset &&
+           (i == 0 ? p.combine == 0 : p.combine != 0) && c->pages.size() == c0->pages.size();
+      if (ok && strategy == IPS_PROGRAM_AUTO && c->runs[0].bit_width == 32 && la->op != IPS_OP_IN) ok = false;
+      for (size_t k = 0; ok && k < c->pages.size(); ++k) ok = c->pages[k].n_rows == c0->pages[k].n_rows;
+      if (!ok) break;
+      PredArgs folded;  // constants that do not fit the chunk's width make their comparison constant
+      run_pred_args(c->runs[0].bit_width, la->op, la->consts, la->n_consts, lb ? p.item.join : 0, lb ? lb->op : 0,
+                    lb ? lb->consts[0] : 0, p.combine, &folded);
+      ChainOpW& o = pa.chain.ops[i];
+      o.w = c->runs[0].bit_width;
+      o.op = folded.op;
+      o.c1 = folded.consts[0];
+      o.combine = p.combine;
+      if (folded.op == IPS_OP_IN) {
+        ok = folded.n_consts <= 16;
+        o.kind = kChainIn;
+        o.n_in = folded.n_consts;
+        for (int j = 0; j < folded.n_consts && j < 16; ++j) o.in_consts[j] = folded.consts[j];
+      } else if (lb) {
+        o.kind = kChainPair;
+        o.join = folded.join;
+        o.op2 = folded.op2;
+        o.c2 = folded.const2;
+      } else {
+        o.kind = kChainSingle;
+      }
+      pa.pg.pages[i] = c->d_pages;
+    }
+    if (ok) {
+      pa.chain.n_ops = pl.n_steps;
+      pa.pg.chunk_rows = n_rows;
+      pa.pg.edges = done ? nullptr : c0->d_edges;  // (a signalling launch merges its shared dwords itself)
+      pa.pg.done = done;
+      pa.pg.done_page0 = 0;
+      pa.pg.done_epoch = done_epoch;
+      uint32_t* bm32 = reinterpret_cast<uint32_t*>(d_bitmap);
+      st = launch_chain_w_pages(pa, (int)c0->pages.size(), c0->runs[0].max_rows, bm32, s);
+      if (st == IPS_OK && pa.pg.edges)
+        st = launch_window_fixup(c0->d_pages, (int)c0->pages.size(), c0->runs[0].max_rows, n_rows, bm32, c0->d_edges, 0, s);
+      if (st == IPS_OK && done && signalled) *signalled = true;
+      if (st != IPS_ERR_UNSUPPORTED) return st;
+      st = IPS_OK;
+    }
+  }
   for (int i = 0; i < pl.n_steps && st == IPS_OK; ++i) {
     const Step& p = pl.steps[i];
     const bool last = i + 1 == pl.n_steps;

@@ -351,3 +351,71 @@ def test_bitmap_batch_counts(capi):
         got = capi.bitmap_batch_counts(bm, n).cpu().numpy()
         exp = np.add.reduceat(bits.astype(np.int64), np.arange(0, n, 2048))
         assert np.array_equal(got, exp), n
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_chunk_program_one_pass_over_common_pages(capi, O, seed, request):
+    """ips_eval_program_chunks on a conjunct / disjunct chain over REQUIRED FLE chunks whose pages hold the SAME
+    rows in every chunk (what a writer that flushes all columns of a row group together produces): ONE launch,
+    blockIdx.y = page, every operand in its own block geometry (ips_chain.hip).  Pages of every awkward size --
+    page starts inside bitmap dwords (edge slots + fix-up), pages smaller than a dword, empty pages -- against
+    numpy on the raw values and against the per-operand plan; constants that do not fit a chunk's width."""
+    request.addfinalizer(lambda: capi.set_program_strategy(capi.PROGRAM_AUTO))
+    rng = np.random.default_rng(900 + seed)
+    n = int(rng.choice([1, 37, 4096, 70001, 300007]))
+    sizes = [RAGGED, [2048, 4096], [1, 5, 31, 33], [70001, 10000, 0], [32, 64, 2048 + 32]][seed]
+    page_rows = cuts(rng, n, sizes)
+    n_ops = int(rng.integers(2, 6))
+    L, AND, OR = capi.leaf, capi.and_node, capi.or_node
+    cmp_np = {O.OP_EQ: np.equal, O.OP_LT: np.less, O.OP_LE: np.less_equal, O.OP_GT: np.greater, O.OP_GE: np.greater_equal}
+    chunks, nodes, exp = [], [], None
+    for i in range(n_ops):
+        w = int(rng.integers(1, 25))
+        span = (1 << w) - 1 if rng.random() < 0.6 else min((1 << w) - 1, 15)
+        v = rng.integers(0, span + 1, n, dtype=np.uint64).astype(np.uint32)
+        ch, _ = fle_chunk(capi, O, v, page_rows, lambda k, w=w: w)
+        chunks.append(ch)
+        kind = rng.integers(0, 3)
+        # now and then a constant beyond the column's width (unsigned SQL meaning: LT / LE always, else never)
+        big = rng.random() < 0.15 and w < 24
+        if kind == 0:
+            op = int(rng.integers(0, 5))
+            c = (1 << w) + 3 if big else int(rng.integers(0, span + 1))
+            nodes.append(L(i, op, c))
+            sel = cmp_np[op](v.astype(np.uint64), np.uint64(c))
+        elif kind == 1:
+            op1, op2 = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+            c1 = int(rng.integers(0, span + 1))
+            c2 = (1 << w) + 1 if big else int(rng.integers(0, span + 1))
+            nodes += [L(i, op1, c1), L(i, op2, c2)]
+            s1, s2 = cmp_np[op1](v.astype(np.uint64), np.uint64(c1)), cmp_np[op2](v.astype(np.uint64), np.uint64(c2))
+            if rng.random() < 0.7:
+                nodes.append(AND())
+                sel = s1 & s2
+            else:
+                nodes.append(OR())
+                sel = s1 | s2
+        else:
+            members = [int(x) for x in rng.integers(0, span + 1, int(rng.integers(1, 17)))]
+            if big:
+                members.append((1 << w) + 7)
+            nodes.append(L(i, O.OP_IN, members))
+            sel = np.isin(v, np.array(members, dtype=np.uint64))
+        if i == 0:
+            exp = sel
+        elif rng.random() < 0.75:
+            nodes.append(AND())
+            exp = exp & sel
+        else:
+            nodes.append(OR())
+            exp = exp | sel
+    for strat in (capi.PROGRAM_AUTO, capi.PROGRAM_PER_OPERAND):
+        capi.set_program_strategy(strat)
+        bm = torch.full(((n + 63) // 64 + 2,), -1, dtype=torch.int64, device="cuda")  # (no zero-initialised bitmap needed)
+        capi.eval_program_chunks(nodes, chunks, bitmap=bm)
+        got_words = words(bm)[:(n + 63) // 64]
+        assert np.array_equal(bits_of(got_words, n), exp), (seed, strat, n, page_rows[:8])
+        if n % 64:
+            assert int(got_words[-1]) >> (n % 64) == 0, "bits behind the last row are zero"
+    for ch in chunks:
+        ch.close()
