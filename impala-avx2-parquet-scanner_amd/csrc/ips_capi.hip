@@ -52,15 +52,20 @@ int device_cus() {
 // Blocks launched per resident block slot.  A grid of exactly the resident size finishes on its
 // slowest CU; smaller work shares let the dispatcher even that out (round 1: 4x, +3..6 % on the
 // w=32 scan and predicate kernels; end of round 2, with the narrow scans at 8 waves per SIMD: 8x is
-// neutral at w=32 and 3-5 % faster at w <= 16, 12x and more cost the early-pruning predicate its
-// prefetch).  Round 3: the predicate-only kernels and the one-pass chain, whose waves spend a few
+// neutral at w=32 and 3-5 % faster at w <= 16; 12x and more cost the early-pruning predicate of that
+// build its prefetch -- today's, with buffer-resource loads, is 5 % faster at 32x).  Round 3: the predicate-only kernels and the one-pass chain, whose waves spend a few
 // hundred instructions per sub-tile, run best with shares of one or two sub-tiles per wave (kind 1 /
-// 2 below; tools/ab/grid_mult_sweep.py).  Dev builds read IPS_GRID_MULT / _PRED / _CHAIN on every call.
+// 2 below; tools/ab/grid_mult_kinds.py, tools/kernel_tour.py with IPS_TOUR_MULTS).  Dev builds read
+// IPS_GRID_MULT / _PRED / _CHAIN / _DECODE / _DICT_DECODE / _SCAN_WIDE on every call.
 int grid_mult(int kind) {
-  const char* e = dev_env(kind == kGridPred ? "IPS_GRID_MULT_PRED" : kind == kGridChain ? "IPS_GRID_MULT_CHAIN" : "IPS_GRID_MULT");
+  static const char* const names[] = {"IPS_GRID_MULT", "IPS_GRID_MULT_PRED", "IPS_GRID_MULT_CHAIN", "IPS_GRID_MULT_DECODE",
+                                      "IPS_GRID_MULT_DICT_DECODE", "IPS_GRID_MULT_SCAN_WIDE"};
+  static const int defaults[] = {8, IPS_GRID_MULT_PRED, IPS_GRID_MULT_CHAIN, IPS_GRID_MULT_DECODE, IPS_GRID_MULT_DICT_DECODE,
+                                 IPS_GRID_MULT_SCAN_WIDE};
+  if (kind < 0 || kind > kGridScanWide) kind = kGridScan;
+  const char* e = dev_env(names[kind]);
   const int v = e ? atoi(e) : 0;
-  if (v > 0) return v;
-  return kind == kGridPred ? IPS_GRID_MULT_PRED : kind == kGridChain ? IPS_GRID_MULT_CHAIN : 8;
+  return v > 0 ? v : defaults[kind];
 }
 
 int grid_for_tiles(const void* kernel, int64_t tiles, int kind) {

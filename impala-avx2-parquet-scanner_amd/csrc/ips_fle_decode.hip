@@ -20,7 +20,7 @@ static ips_status launch_decode_one(const uint64_t* enc, int64_t n_rows, void* o
   using GT = typename GatherT<G>::type;
   auto kern = fle_decode_kernel<W, OW, G>;
   const int64_t tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
-  int grid = grid_for_tiles(reinterpret_cast<const void*>(kern), tiles);
+  int grid = grid_for_tiles(reinterpret_cast<const void*>(kern), tiles, G == 0 ? kGridDecode : kGridDictDecode);
   if (grid <= 0) return IPS_ERR_HIP;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, s, enc, n_rows, out,
                      reinterpret_cast<const GT*>(dict), dict_entries, bad_index, 0u);

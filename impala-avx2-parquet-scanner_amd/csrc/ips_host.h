@@ -63,7 +63,7 @@ ips_status hip_fail(hipError_t e, const char* what);
 
 // Blocks to launch for a grid-stride kernel over 'tiles' wave sub-tiles: enough to fill every CU
 // at the kernel's occupancy, never more than the work.  Occupancy is queried once per kernel.
-enum GridKind { kGridScan = 0, kGridPred = 1, kGridChain = 2 };  // grid_mult
+enum GridKind { kGridScan = 0, kGridPred = 1, kGridChain = 2, kGridDecode = 3, kGridDictDecode = 4, kGridScanWide = 5 };  // grid_mult
 int grid_for_tiles(const void* kernel, int64_t tiles, int kind = kGridScan);
 int device_cus();
 int grid_mult(int kind = kGridScan);

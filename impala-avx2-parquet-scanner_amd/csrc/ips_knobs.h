@@ -16,7 +16,8 @@
     defined(IPS_GATHER_WIDE) || defined(IPS_GATHER_MAX_4) || defined(IPS_QUADS) || defined(IPS_QUADS16) || \
     defined(IPS_PHASE_B_GROUP) || defined(IPS_NT_VALUE_STORE) || defined(IPS_DECODE_PACKED) ||          \
     defined(IPS_EXP_ROUNDS) || defined(IPS_AUX_NT) || defined(IPS_PLAIN_ABLATE) || defined(IPS_MIN_SHARE) || defined(IPS_PLAIN_DENSE8) ||  \
-    defined(IPS_WINDOW_ABLATE) || defined(IPS_GRID_MULT_PRED) || defined(IPS_GRID_MULT_CHAIN)
+    defined(IPS_WINDOW_ABLATE) || defined(IPS_GRID_MULT_PRED) || defined(IPS_GRID_MULT_CHAIN) ||  \
+    defined(IPS_GRID_MULT_DECODE) || defined(IPS_GRID_MULT_DICT_DECODE) || defined(IPS_GRID_MULT_SCAN_WIDE)
 #error "development switches need -DIPS_DEV_KNOBS (the default library has none)"
 #endif
 #endif
@@ -88,6 +89,15 @@
 // ---- grid sizes (ips_capi.hip: grid_mult) ----------------------------------------------------
 #ifndef IPS_GRID_MULT_PRED
 #define IPS_GRID_MULT_PRED 32       // workgroups per resident slot: stand-alone FLE predicate kernels of w >= 6 (w = 12: 71 -> 67 us)
+#endif
+#ifndef IPS_GRID_MULT_SCAN_WIDE
+#define IPS_GRID_MULT_SCAN_WIDE 16  // ... fused scans of w >= 16 (w = 32 @1 / 10 / 30 %: 192 / 209 / 265 us at 8x, 188 / 205 / 260 at 16x)
+#endif
+#ifndef IPS_GRID_MULT_DECODE
+#define IPS_GRID_MULT_DECODE 16     // ... fle_decode (w = 32 / 16 / 8: 378 / 174 / 85 us at 8x, 362 / 169 / 83 at 16x)
+#endif
+#ifndef IPS_GRID_MULT_DICT_DECODE
+#define IPS_GRID_MULT_DICT_DECODE 32  // ... dictionary decode with a per-workgroup dictionary copy (D = 4096: 277 -> 247 us)
 #endif
 #ifndef IPS_GRID_MULT_CHAIN
 #define IPS_GRID_MULT_CHAIN 64      // ... the one-pass conjunct chain (Q6 shape: 8x 297 us, 16x 289, 32x 284, 64x = one stripe per wave 279)

@@ -24,7 +24,27 @@ W = (n + 63) // 64
 REPS = 5
 
 
+MULTS = [int(x) for x in os.environ.get("IPS_TOUR_MULTS", "").split(",") if x]
+
+
 def run(op, kernel, byts, fn):
+    if MULTS:  # dev builds (-DIPS_DEV_KNOBS read IPS_GRID_MULT on every call): every multiplier, interleaved
+        res = {m: [] for m in MULTS}
+        for _ in range(3):
+            for m in MULTS:
+                os.environ["IPS_GRID_MULT"] = str(m)
+                fn()
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(REPS):
+                    fn()
+                b.record()
+                torch.cuda.synchronize()
+                res[m].append(a.elapsed_time(b) * 1e3 / REPS)
+        os.environ.pop("IPS_GRID_MULT", None)
+        print(f"{op[:86]:86s} " + "  ".join(f"x{m}: {sorted(res[m])[1]:7.1f}" for m in MULTS), flush=True)
+        return
     fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
