@@ -435,3 +435,37 @@ def _pack_rows(mask):
     if pad:
         mask = torch.cat([mask, torch.zeros(pad, dtype=torch.bool, device=mask.device)])
     return _pack(mask)
+
+
+def test_one_pass_chain_with_more_stripes_than_waves(capi, request):
+    """The one-pass conjunct chain launches one 2048-row stripe per wave up to 64 workgroups per resident
+    slot; beyond that (here 2^31 + 70 000 rows of two 1-bit columns: 1 048 611 stripes) a wave loops over several
+    stripes with the next one prefetched.  A 1-bit FLE column IS its plane words (row k of a block at bit
+    63 - k), so random words are the encoded columns and (c0 == 1) AND (c1 == 1) must be the bit-reversed
+    AND of the words: popcount over everything, every word of the first and last 2^16 blocks, and equality
+    with the per-operand plan."""
+    request.addfinalizer(lambda: capi.set_program_strategy(capi.PROGRAM_AUTO))
+    n = (1 << 31) + 70000
+    n_words = (n + 63) // 64
+    g = torch.Generator(device="cuda")
+    g.manual_seed(2031)
+    enc = [torch.randint(-(1 << 63), (1 << 63) - 1, (n_words + 2,), dtype=torch.int64, device="cuda", generator=g)
+           for _ in range(2)]
+    cols = [capi.fle_column(enc[0], 1), capi.fle_column(enc[1], 1)]
+    nodes = [capi.leaf(0, capi.OP_EQ, 1), capi.leaf(1, capi.OP_EQ, 1), capi.and_node()]
+    capi.set_program_strategy(capi.PROGRAM_ONE_PASS)
+    got = capi.eval_program(nodes, cols, n).clone()
+    both = enc[0][:n_words] & enc[1][:n_words]
+    tail = n % 64  # rows of the last block: its high 'tail' bits
+    both[-1] &= -(1 << (64 - tail))
+    assert capi.bitmap_count(got, n) == capi.bitmap_count(both, n_words * 64)
+
+    def bitrev(a):
+        a = a.view(np.uint8).reshape(-1, 8)[:, ::-1]
+        return np.packbits(np.unpackbits(a, axis=1, bitorder="big"), axis=1, bitorder="little").view(np.uint64).ravel()
+
+    for lo, hi in ((0, 1 << 16), (n_words - (1 << 16), n_words), (n_words // 2, n_words // 2 + 4096)):
+        assert np.array_equal(words(got[lo:hi]), bitrev(both[lo:hi].cpu().numpy())), (lo, hi)
+    capi.set_program_strategy(capi.PROGRAM_PER_OPERAND)
+    ref = capi.eval_program(nodes, cols, n)
+    assert torch.equal(ref, got)
