@@ -307,7 +307,7 @@ def leg_page_lists(ips, capi, dev):
     encs = [capi.fle_encode(codes[c], q6.COLUMNS[c][3]) for c in range(3)]
     nodes, cols = q6.program(capi, encs)
     ref = capi.eval_program(nodes, cols, n)
-    t_c, _ = time_launches(lambda: capi.eval_program(nodes, cols, n, bitmap=ref))
+    t_c, _ = time_launches(lambda: capi.eval_program(nodes, cols, n, bitmap=ref), reps=20, warm=5)
     del encs, cols
     bm = torch.empty_like(ref)
     # pages that hold the same rows in every column: the one-pass chain, blockIdx.y = page (1 launch; with
@@ -319,7 +319,7 @@ def leg_page_lists(ips, capi, dev):
                                    ("pages of 2^20 / 2^20 - 37 / 700,001 rows (page ends differ between the columns)",
                                     (1 << 20, (1 << 20) - 37, 700001), 5)):
         chunks = [chunk_of(codes[c], q6.COLUMNS[c][3], sizes[c]) for c in range(3)]
-        tmed, tmin = time_launches(lambda: capi.eval_program_chunks(nodes, chunks, bitmap=bm))
+        tmed, tmin = time_launches(lambda: capi.eval_program_chunks(nodes, chunks, bitmap=bm), reps=20, warm=5)
         out.append(rec(f"configs[4] Q6 conjunction over page lists, {label}", n, q6.algorithmic_bytes(n), tmed, tmin,
                        bool(torch.equal(bm, ref)), vs_contiguous=round(tmed / t_c, 3),
                        launches_per_step=launches))

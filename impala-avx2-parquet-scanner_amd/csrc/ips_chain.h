@@ -50,7 +50,7 @@ struct ChainArgsW {
 // The same chain over column chunks held as page lists whose pages hold the same rows in every operand's
 // chunk (blockIdx.y = page; ips_chunk_device.h): per operand the device page table (first page of the launch)
 struct ChainPagesArgs {
-  const void* pages[kChainWMaxOps];  // ChunkPage tables
+  const void* slot_pages[kChainWMaxSlots];  // per load slot: its operand's ChunkPage table (unused slots: operand 0's)
   int64_t chunk_rows;
   uint32_t* edges;       // edge slots of the chunk-wide bitmap or NULL (ips_chunk_device.h)
   uint32_t* done;        // a sharded step's page counters or NULL (page_done)
@@ -58,14 +58,16 @@ struct ChainPagesArgs {
   uint32_t done_epoch;
 };
 struct ChainPagedArgsW {
-  ChainArgsW chain;      // slots[i].rsrc[0] = the slot's operand (the resources are made per page)
+  ChainArgsW chain;      // (the slots' resources are made per page)
   ChainPagesArgs pg;
 };
 
 // IPS_ERR_UNSUPPORTED: the chain does not fit the kernel (more than kChainWMaxSlots load slots, a
 // column of 4 GiB or more) -- the caller falls back to the per-operand plan
 ips_status launch_chain_w(ChainArgsW& a, const void* const* enc, int64_t n_rows, uint32_t* bitmap32, hipStream_t s);
-// pa.chain.ops[0..n_ops) and pa.pg filled by the caller; n_pages pages of at most max_rows rows
-ips_status launch_chain_w_pages(ChainPagedArgsW& pa, int n_pages, int64_t max_rows, uint32_t* bitmap32, hipStream_t s);
+// pa.chain.ops[0..n_ops) and pa.pg (but slot_pages) filled by the caller; op_pages[i] = operand i's device page
+// table (first page of the launch); n_pages pages of at most max_rows rows
+ips_status launch_chain_w_pages(ChainPagedArgsW& pa, const void* const* op_pages, int n_pages, int64_t max_rows,
+                                uint32_t* bitmap32, hipStream_t s);
 
 }  // namespace ips

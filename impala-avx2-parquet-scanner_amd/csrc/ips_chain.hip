@@ -165,8 +165,13 @@ __device__ __forceinline__ void chain_body(ChainArgsK a, ChainPagedArgsK pa, int
   uint32_t* lds32 = lds_all + wave * a->image_dwords;
   [[maybe_unused]] ChunkPage pg;
   [[maybe_unused]] BitmapWindow win;
+  // PAGED: the page's bytes in every slot's operand, fetched side by side before anything depends on them
+  // (slot by slot inside the loads, the two scalar loads per slot formed a chain of twelve)
+  [[maybe_unused]] const uint64_t* slot_base[LTOT];
   if constexpr (PAGED) {
-    pg = reinterpret_cast<const ChunkPage*>(pa->pg.pages[0])[blockIdx.y];
+    pg = reinterpret_cast<const ChunkPage*>(pa->pg.slot_pages[0])[blockIdx.y];
+#pragma unroll
+    for (int i = 0; i < LTOT; ++i) slot_base[i] = reinterpret_cast<const ChunkPage*>(pa->pg.slot_pages[i])[blockIdx.y].data;
     n_rows = pg.n_data;
     win = bitmap_window(bitmap32, pg, pa->pg.chunk_rows, pa->pg.done, pa->pg.edges);
   }
@@ -192,11 +197,9 @@ __device__ __forceinline__ void chain_body(ChainArgsK a, ChainPagedArgsK pa, int
     const uint32_t in_tile = first + lane_byte;
     const uint32_t off = in_tile < tile_bytes ? (uint32_t)t * tile_bytes + in_tile : 0xFFFFFFF0u;
     if constexpr (PAGED) {  // over the page's bytes in this operand's chunk
-      const ChunkPage* pages = reinterpret_cast<const ChunkPage*>(pa->pg.pages[a->slots[i].rsrc[0]]);
-      const uint64_t* base = pages[blockIdx.y].data;
       const int64_t bytes = ((n_rows + 63) / 64) * (int64_t)(tile_bytes >> 5);
-      r[i] = buffer_load16<true>(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(base), 0, tile_bytes ? (int)bytes : 0,
-                                                                   kBufferRsrcDword3), off);
+      r[i] = buffer_load16<true>(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(slot_base[i]), 0,
+                                                                   tile_bytes ? (int)bytes : 0, kBufferRsrcDword3), off);
     } else {
       r[i] = buffer_load16<true>(host_rsrc(a->slots[i].rsrc[0], a->slots[i].rsrc[1], a->slots[i].rsrc[2], a->slots[i].rsrc[3]), off);
     }
@@ -383,10 +386,13 @@ ips_status launch_chain_w(ChainArgsW& a, const void* const* enc, int64_t n_rows,
   IPS_CHAIN_DISPATCH(launch_chain_w_class, a.n_slots, maxw, a, n_rows, bitmap32, s);
 }
 
-ips_status launch_chain_w_pages(ChainPagedArgsW& pa, int n_pages, int64_t max_rows, uint32_t* bitmap32, hipStream_t s) {
+ips_status launch_chain_w_pages(ChainPagedArgsW& pa, const void* const* op_pages, int n_pages, int64_t max_rows,
+                                uint32_t* bitmap32, hipStream_t s) {
   int maxw = 0;
   const ips_status st = chain_layout(pa.chain, nullptr, (max_rows + 63) / 64, &maxw);
   if (st != IPS_OK) return st;
+  for (int i = 0; i < kChainWMaxSlots; ++i)
+    pa.pg.slot_pages[i] = op_pages[i < pa.chain.n_slots ? (int)pa.chain.slots[i].rsrc[0] : 0];
   IPS_CHAIN_DISPATCH(launch_chain_w_pages_class, pa.chain.n_slots, maxw, pa, n_pages, max_rows, bitmap32, s);
 }
 

@@ -964,6 +964,7 @@ ips_status eval_program_chunks_signalled(const ips_node* nodes, int n_nodes, con
       (strategy == IPS_PROGRAM_AUTO || strategy == IPS_PROGRAM_ONE_PASS)) {
     ChainPagedArgsW pa;
     memset(&pa, 0, sizeof(pa));
+    const void* op_pages[kChainWMaxOps];
     bool ok = true;
     const ips_chunk* c0 = chunks[pl.steps[0].item.a->column];
     for (int i = 0; i < pl.n_steps && ok; ++i) {
@@ -997,7 +998,7 @@ ips_status eval_program_chunks_signalled(const ips_node* nodes, int n_nodes, con
       } else {
         o.kind = kChainSingle;
       }
-      pa.pg.pages[i] = c->d_pages;
+      op_pages[i] = c->d_pages;
     }
     if (ok) {
       pa.chain.n_ops = pl.n_steps;
@@ -1007,7 +1008,7 @@ ips_status eval_program_chunks_signalled(const ips_node* nodes, int n_nodes, con
       pa.pg.done_page0 = 0;
       pa.pg.done_epoch = done_epoch;
       uint32_t* bm32 = reinterpret_cast<uint32_t*>(d_bitmap);
-      st = launch_chain_w_pages(pa, (int)c0->pages.size(), c0->runs[0].max_rows, bm32, s);
+      st = launch_chain_w_pages(pa, op_pages, (int)c0->pages.size(), c0->runs[0].max_rows, bm32, s);
       if (st == IPS_OK && pa.pg.edges)
         st = launch_window_fixup(c0->d_pages, (int)c0->pages.size(), c0->runs[0].max_rows, n_rows, bm32, c0->d_edges, 0, s);
       if (st == IPS_OK && done && signalled) *signalled = true;

@@ -201,4 +201,14 @@ encs = [capi.fle_encode(codes[c], q6.COLUMNS[c][3]) for c in range(3)]
 del codes
 nodes, cols = q6.program(capi, encs)
 bmq = torch.empty((nq + 63) // 64, dtype=torch.int64, device=dev)
-run("Q6 conjunction, 3 columns (3 launches)", "fle_pred_w_kernel<12, 1>", q6.algorithmic_bytes(nq), lambda: capi.eval_program(nodes, cols, nq, bitmap=bmq))
+run("Q6 conjunction, 3 columns, one-pass chain (1 launch)", "fle_chain_w_kernel<6, 16>", q6.algorithmic_bytes(nq),
+    lambda: capi.eval_program(nodes, cols, nq, bitmap=bmq))
+
+
+def q6_per_operand():
+    capi.set_program_strategy(capi.PROGRAM_PER_OPERAND)
+    capi.eval_program(nodes, cols, nq, bitmap=bmq)
+    capi.set_program_strategy(capi.PROGRAM_AUTO)
+
+
+run("Q6 conjunction, 3 columns, per-operand plan (3 launches)", "fle_pred_w_kernel<12, 1>", q6.algorithmic_bytes(nq), q6_per_operand)

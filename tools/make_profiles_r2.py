@@ -137,7 +137,8 @@ with open(os.path.join(dst, f"{tag}_kernel_tour.md"), "w") as f:
            "fle_pred w=8 BETWEEN": "fle_pred_w_kernel<8, 1>", "fle_pred w=16 LT": "fle_pred_w_kernel<16, 0>",
            "fle_pred w=8 LT": "fle_pred_w_kernel<8, 0>", "fle_pred w=32 LT": "fle_pred32_early_kernel<32, false>",
            "nullable leaf w=12, 10% NULL (counts + leaf)": "fle_leaf_kernel<12, 0>", "bitmap_expand (root 50%)": "expand_kernel<0, 0>",
-           "Q6 conjunction, 3 columns (3 launches)": "fle_pred_w_kernel<12, 1>"}
+           "Q6 conjunction, 3 columns, one-pass chain (1 launch)": "fle_chain_w_kernel<6, 16>",
+           "Q6 conjunction, 3 columns, per-operand plan (3 launches)": "fle_pred_w_kernel<12, 1>"}
     for t in tour:
         t["kernel"] = fix.get(t["op"], t["kernel"])
         ks = largest(ttrace, t["kernel"], "Grid_Size_X")
@@ -149,7 +150,7 @@ with open(os.path.join(dst, f"{tag}_kernel_tour.md"), "w") as f:
         sqv = defaultdict(list)
         for r in largest(tsq, t["kernel"]):
             sqv[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        n_tiles = (1 << 28) / 2048
+        n_tiles = (600037902 if t["op"].startswith("Q6") else (1 << 28)) / 2048
         valu = statistics.mean(sqv["SQ_INSTS_VALU"]) / n_tiles if sqv.get("SQ_INSTS_VALU") else None
         ldsi = statistics.mean(sqv["SQ_INSTS_LDS"]) / n_tiles if sqv.get("SQ_INSTS_LDS") else None
         conf = (statistics.mean(sqv["SQ_LDS_BANK_CONFLICT"]) / max(statistics.mean(sqv["SQ_LDS_IDX_ACTIVE"]), 1)
