@@ -138,7 +138,7 @@ run("assemble_tuples 3 x int32 -> 16 B", "assemble_small_kernel<16>", nsel * 28 
 del vals, enc, outs, bm50, acc, tuples, dense
 
 # dictionary decode with a dictionary shared by one workgroup per CU (beyond 32 KiB), and the largest one
-for Db, bwb, kname in ((16384, 14, "fle_decode_kernel<14, 4, 4, 16"), (40000, 16, "fle_decode_kernel<16, 4, 4, 4")):
+for Db, bwb, kname in ((16384, 14, "fle_decode_kernel<14, 4, 4, 16"), (40000, 16, "fle_decode_kernel<16, 4, 4, 8, true, true>")):
     rngb = np.random.default_rng(Db)
     dvb = np.sort(rngb.choice(np.arange(-2 ** 30, 2 ** 30, 7), Db, replace=False)).astype(np.int32)
     cb = ((capi.synth_u32(ips.synth.SEED_DICT, n, 32).to(torch.int64) & 0xFFFFFFFF) % Db).to(torch.int32)
