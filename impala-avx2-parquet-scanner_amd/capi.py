@@ -47,6 +47,7 @@ SYMBOLS = [
     "ips_bitmap_and", "ips_bitmap_or", "ips_bitmap_fill", "ips_bitmap_count", "ips_bitmap_batch_counts",
     "ips_expand_workspace_bytes", "ips_bitmap_expand",
     "ips_eval_program", "ips_set_program_strategy", "ips_synth_splitmix_u32",
+    "ips_chunk_select_nullable", "ips_chunk_select_nullable_workspace_bytes",
     "ips_inset_open", "ips_dict_inset_open", "ips_inset_close", "ips_inset_size", "ips_fle_pred_inset",
     "ips_fle_scan_inset", "ips_dict_scan_inset",
     "ips_chunk_open", "ips_chunk_close", "ips_chunk_num_rows", "ips_chunk_num_batches", "ips_chunk_num_pages",
@@ -765,6 +766,23 @@ class Chunk:
 
     def compact(self, bvals, counts, stream=None):
         return batches_compact(bvals, counts, self.n_batches * BATCH_ROWS, stream=stream)
+
+    def select_nullable(self, selection, dict_=None, stream=None):
+        """ips_chunk_select_nullable on an OPTIONAL chunk -> (dense values of the selected NOT-NULL rows,
+        NOT-NULL flag words of the selected rows, n_selected, n_values, bad_index); synchronises for the counts."""
+        L = lib()
+        L.ips_chunk_select_nullable_workspace_bytes.restype = C.c_size_t
+        L.ips_chunk_select_nullable_workspace_bytes.argtypes = [C.c_void_p]
+        need = int(L.ips_chunk_select_nullable_workspace_bytes(self.h))
+        ws = torch.empty(need + 16, dtype=torch.uint8, device=self.device)
+        dt = TORCH_SLOT[dict_.type] if dict_ else torch.int32
+        dense = torch.empty(max(self.n_rows, 4), dtype=dt, device=self.device)
+        flags = torch.empty(max(_words(self.n_rows), 2), dtype=torch.int64, device=self.device)
+        counts = torch.empty(3, dtype=torch.int64, device=self.device)
+        _ck(L.ips_chunk_select_nullable(self.h, dict_.h if dict_ else None, _ptr(selection), _ptr(dense), _ptr(flags),
+                                        _ptr(counts), _ptr(ws), _stream(stream)))
+        c = counts.cpu().tolist()
+        return dense[:c[1]], flags[:_words(c[0])], int(c[0]), int(c[1]), int(c[2])
 
 
 def eval_program_chunks(nodes, chunks, bitmap=None, workspace=None, stream=None):

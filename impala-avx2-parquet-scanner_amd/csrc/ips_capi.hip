@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "ips_fle_kernels.h"
+#include "ips_chunk_host.h"
 #include "ips_host.h"
 
 namespace ips {
@@ -1064,6 +1065,7 @@ ips_status ips_dict_select_nullable(const ips_dict* dict, const void* d_def_leve
     const int64_t n_data = n_data_rows < n_rows ? n_data_rows : n_rows;
     if (n_data > 0) {
       SelNullArgs a;
+      memset(&a, 0, sizeof(a));  // (pages = NULL: one buffer per column)
       a.root = reinterpret_cast<const unsigned long long*>(root);
       a.sel = reinterpret_cast<const unsigned long long*>(d_selection);
       a.c_r = w.rank;
@@ -1105,6 +1107,81 @@ ips_status ips_dict_select_nullable(const ips_dict* dict, const void* d_def_leve
   }
   // 3. the NOT-NULL flag of every selected row (the NULL indicator bit, :1022-1026)
   return launch_compress(0, d_selection, root_kind, root, n_rows, d_nonnull_flags, d_counts, w.rank, s);
+}
+
+// The same over an OPTIONAL column chunk held as a page list: four launches whatever the number of pages
+// (+ one more per further run of pages of another code width).
+namespace {
+struct ChunkSelNullWs {
+  uint64_t* sel_copy;
+  uint32_t *c_r, *c_s, *c_rs;
+  uint64_t *page_s, *page_rs;
+  size_t total;
+};
+ChunkSelNullWs chunk_sel_null_ws(void* base, const ips_chunk* c) {
+  uint8_t* p = reinterpret_cast<uint8_t*>(base);
+  ChunkSelNullWs w;
+  size_t off = 0;
+  w.sel_copy = reinterpret_cast<uint64_t*>(p + off); off += align256((size_t)c->n_batches * (IPS_BATCH_ROWS / 64) * 8 + 16);
+  w.c_r = reinterpret_cast<uint32_t*>(p + off); off += align256((size_t)c->rank_entries * 4);
+  w.c_s = reinterpret_cast<uint32_t*>(p + off); off += align256((size_t)c->rank_entries * 4);
+  w.c_rs = reinterpret_cast<uint32_t*>(p + off); off += align256((size_t)c->rank_entries * 4);
+  w.page_s = reinterpret_cast<uint64_t*>(p + off); off += align256(c->pages.size() * 8);
+  w.page_rs = reinterpret_cast<uint64_t*>(p + off); off += align256(c->pages.size() * 8);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+size_t ips_chunk_select_nullable_workspace_bytes(const ips_chunk* chunk) {
+  if (!chunk || chunk->max_def_level <= 0) return 0;
+  return chunk_sel_null_ws(nullptr, chunk).total;
+}
+
+ips_status ips_chunk_select_nullable(const ips_chunk* chunk, const ips_dict* dict, const uint64_t* d_selection,
+                                     void* d_dense_values, uint64_t* d_nonnull_flags, int64_t* d_counts,
+                                     void* d_workspace, ips_stream stream) {
+  IPS_REQUIRE(chunk != nullptr, "ips_chunk_select_nullable: NULL chunk");
+  IPS_REQUIRE(chunk->encoding == IPS_COL_FLE && chunk->max_def_level > 0,
+              "ips_chunk_select_nullable: an OPTIONAL FLE / dictionary chunk (REQUIRED chunks: ips_chunk_select)");
+  IPS_REQUIRE(d_counts != nullptr, "ips_chunk_select_nullable: NULL counts");
+  hipStream_t s = S(stream);
+  IPS_HIP_TRY(hipMemsetAsync(d_counts, 0, 24, s));  // (also the bad-index flag, set by the kernels)
+  if (chunk->n_rows == 0 || chunk->pages.empty()) return IPS_OK;
+  IPS_REQUIRE(d_selection && aligned16(d_selection) && d_dense_values && aligned16(d_dense_values) && d_nonnull_flags &&
+                  aligned16(d_nonnull_flags) && d_workspace && aligned16(d_workspace),
+              "ips_chunk_select_nullable: NULL or misaligned argument");
+  for (const ips_chunk::Run& run : chunk->runs)
+    IPS_REQUIRE(!dict || run.bit_width <= 16, "ips_chunk_select_nullable: code width %d > 16", run.bit_width);
+  const ChunkSelNullWs w = chunk_sel_null_ws(d_workspace, chunk);
+  // the flag words (one bit per selected row, at most one per row): the select kernel ORs its segment ends in
+  IPS_HIP_TRY(hipMemsetAsync(d_nonnull_flags, 0, (size_t)((chunk->n_rows + 63) / 64) * 8, s));
+  int64_t max_rows = 0;
+  for (const ips_chunk::Run& run : chunk->runs) max_rows = run.max_rows > max_rows ? run.max_rows : max_rows;
+  ips_status st = launch_selnull_pages_prepare(chunk->d_pages, (int)chunk->pages.size(), max_rows, d_selection, chunk->n_rows,
+                                               w.sel_copy, w.c_r, w.c_s, w.c_rs, w.page_s, w.page_rs, d_counts, s);
+  if (st != IPS_OK) return st;
+  for (const ips_chunk::Run& run : chunk->runs) {
+    if (run.max_data <= 0) continue;  // (pages of NULLs only: their flags are zero already)
+    SelNullArgs a;
+    memset(&a, 0, sizeof(a));
+    a.c_r = w.c_r;
+    a.c_s = w.c_s;
+    a.c_rs = w.c_rs;
+    a.flags = reinterpret_cast<unsigned long long*>(d_nonnull_flags);
+    a.bad_index = d_counts + 2;
+    a.n_rows = run.max_rows;
+    a.root_kind = kRootLevels1;
+    a.pages = chunk->d_pages + run.first;
+    a.n_pages = run.count;
+    a.sel_copy = reinterpret_cast<const unsigned long long*>(w.sel_copy);
+    a.page_s = reinterpret_cast<const unsigned long long*>(w.page_s) + run.first;
+    a.page_rs = reinterpret_cast<const unsigned long long*>(w.page_rs) + run.first;
+    st = launch_fle_selnull(run.bit_width, dict ? dict->slot : 0, nullptr, 0, a, d_dense_values,
+                            dict ? dict->d_entries : nullptr, dict ? (uint32_t)dict->n : 0u, nullptr, s);
+    if (st != IPS_OK) return st;
+  }
+  return IPS_OK;
 }
 
 // ---- PLAIN ----------------------------------------------------------------------------------

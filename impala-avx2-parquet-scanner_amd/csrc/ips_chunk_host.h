@@ -56,6 +56,12 @@ ips_status launch_plain_select_pages(int stride_bytes, const ChunkPage* d_pages,
 // edge mode's second launch over the same pages (ips_chunk.hip)
 ips_status launch_window_fixup(const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
                                uint32_t* bitmap32, const uint32_t* edges, int combine, hipStream_t s);
+// ips_chunk_select_nullable's first three launches (ips_rank.hip): the pages' selections as aligned bitmaps, the
+// three count tables per page, the pages' first selected / first selected NOT-NULL row and the totals
+ips_status launch_selnull_pages_prepare(const ChunkPage* d_pages, int n_pages, int64_t max_rows, const uint64_t* d_sel,
+                                        int64_t chunk_rows, uint64_t* sel_copy, uint32_t* c_r, uint32_t* c_s,
+                                        uint32_t* c_rs, uint64_t* page_s, uint64_t* page_rs, int64_t* counts,
+                                        hipStream_t s);
 // tile counts of every page's definition levels (ips_rank.hip): page p's table at counts + page.rank0
 ips_status launch_rank_counts_pages(const ChunkPage* d_pages, int n_pages, int64_t max_rows, uint32_t* counts,
                                     hipStream_t s);

@@ -1033,14 +1033,26 @@ struct SelNullArgs {
   int64_t* bad_index;         // set non-zero when a selected code lies outside the dictionary
   int64_t n_rows;
   int32_t root_kind;
+  // over a column chunk held as a page list (ips_chunk_select_nullable; blockIdx.y = page, else NULL): the page's
+  // levels / data blocks / rank tables come from its descriptor, its selection from an aligned copy of the
+  // chunk-wide one (sel_copy + 32 words per earlier batch), and the page's first selected row / first selected
+  // NOT-NULL row continue the earlier pages' (page_s / page_rs, exclusive prefix sums over the pages)
+  const ChunkPage* pages;
+  int32_t n_pages;       // (grid.y of the launch; n_rows = rows of the largest page)
+  int32_t reserved;
+  const unsigned long long* sel_copy;
+  const unsigned long long* page_s;
+  const unsigned long long* page_rs;
 };
 
 template <int W, int G>
 __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_select_nullable_kernel(
-    const uint64_t* __restrict__ enc, int64_t n_data, SelNullArgs a,
+    const uint64_t* __restrict__ enc_arg, int64_t n_data_arg, SelNullArgs a,
     typename GatherT<G>::type* __restrict__ dense, const typename GatherT<G>::type* __restrict__ dict,
     uint32_t dict_entries, int64_t* __restrict__ n_values) {
   using GT = typename GatherT<G>::type;
+  const uint64_t* __restrict__ enc = enc_arg;
+  int64_t n_data = n_data_arg;
   constexpr int kRegionBytes = plane_tile_bytes(W);
   constexpr int kSegWords64 = kLeafSegDwords / 2 + 2;  // the wave's data-row selection, <= 257 words used
   constexpr uint32_t kListMax = 1024;                  // index-list window (entries of 16 bits)
@@ -1061,7 +1073,26 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_select_nul
 
   const u64* __restrict__ root = a.root;
   const u64* __restrict__ sel = a.sel;
-  const int64_t n_rows = a.n_rows;
+  const uint32_t* __restrict__ c_r = a.c_r;
+  const uint32_t* __restrict__ c_s = a.c_s;
+  const uint32_t* __restrict__ c_rs = a.c_rs;
+  int64_t n_rows = a.n_rows;
+  u64 page_s = 0, page_rs = 0;
+  const bool paged = a.pages != nullptr;  // wave-uniform
+  if (paged) {
+    const ChunkPage pg = a.pages[blockIdx.y];
+    if ((int64_t)blockIdx.x * kExpWordsPerBlock * 64 >= pg.n_rows) return;  // (the grid is sized for the largest page)
+    enc = pg.data;
+    n_data = pg.n_data;
+    root = reinterpret_cast<const u64*>(pg.levels);
+    sel = a.sel_copy + (size_t)pg.batch0 * (kRowsPerTile / 64);
+    n_rows = pg.n_rows;
+    c_r += pg.rank0;
+    c_s += pg.rank0;
+    c_rs += pg.rank0;
+    page_s = a.page_s[blockIdx.y];
+    page_rs = a.page_rs[blockIdx.y];
+  }
   const int64_t n_words = (n_rows + 63) / 64;
   const int64_t tiles = (n_words + kRankWordsPerTile - 1) / kRankWordsPerTile;
   const int64_t first = (int64_t)blockIdx.x * kExpWordsPerBlock + wave * kExpWordsPerWave;
@@ -1075,14 +1106,14 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_select_nul
   const int part_waves = (int)(blockIdx.x % kExpBlocksPerTile) * (kRankWaves / kExpBlocksPerTile);
   uint32_t before_r = 0, before_s = 0, before_rs = 0;
   for (int64_t i = threadIdx.x; i < tile; i += kRankThreads) {
-    before_r += a.c_r[i];
-    before_s += a.c_s[i];
-    before_rs += a.c_rs[i];
+    before_r += c_r[i];
+    before_s += c_s[i];
+    before_rs += c_rs[i];
   }
   if ((int)threadIdx.x < part_waves) {
-    before_r += a.c_r[tiles + tile * kRankWaves + threadIdx.x];
-    before_s += a.c_s[tiles + tile * kRankWaves + threadIdx.x];
-    before_rs += a.c_rs[tiles + tile * kRankWaves + threadIdx.x];
+    before_r += c_r[tiles + tile * kRankWaves + threadIdx.x];
+    before_s += c_s[tiles + tile * kRankWaves + threadIdx.x];
+    before_rs += c_rs[tiles + tile * kRankWaves + threadIdx.x];
   }
   {
     const uint32_t lo = wave_sum(before_r & 0xFFFFu), hi = wave_sum(before_r >> 16);
@@ -1116,14 +1147,14 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_select_nul
   }
   __syncthreads();
   u64 base_r = part_r[0] + part_r[1] + part_r[2] + part_r[3];
-  u64 base_s = part_s[0] + part_s[1] + part_s[2] + part_s[3];
-  u64 base_rs = part_rs[0] + part_rs[1] + part_rs[2] + part_rs[3];
+  u64 base_s = page_s + part_s[0] + part_s[1] + part_s[2] + part_s[3];
+  u64 base_rs = page_rs + part_rs[0] + part_rs[1] + part_rs[2] + part_rs[3];
   for (int w = 0; w < wave; ++w) {
     base_r += tot_r[w];
     base_s += tot_s[w];
     base_rs += tot_rs[w];
   }
-  if (a.n_selected && blockIdx.x == gridDim.x - 1 && threadIdx.x == kRankThreads - 1)
+  if (!paged && a.n_selected && blockIdx.x == gridDim.x - 1 && threadIdx.x == kRankThreads - 1)
     *a.n_selected = (int64_t)(base_s + run_s);  // last wave of the last block: popcount(selection)
 
   // the NOT-NULL flag of every selected row (the NULL indicator bit, hdfs-parquet-scanner.cc:
@@ -1290,7 +1321,7 @@ __global__ __launch_bounds__(kThreads, IPS_MIN_WAVES_PER_EU) void fle_select_nul
   }
 
   // the number of values: the wave that holds the end of the data buffer knows it, else the last wave
-  if (n_values && lane == 0) {
+  if (!paged && n_values && lane == 0) {  // (paged: the page prefix kernel knows both totals)
     const bool last = blockIdx.x == gridDim.x - 1 && wave == kRankWaves - 1;
     const u64 nd = (u64)n_data;
     if ((base_r <= nd && nd < base_r + run_r) || (last && nd >= base_r + run_r)) *n_values = (int64_t)out_pos;

@@ -221,7 +221,7 @@ static ips_status launch_selnull_w(int gather, const uint64_t* enc, int64_t n_da
                                    void* dense, const void* dict, uint32_t dict_entries, int64_t* n_values,
                                    hipStream_t s) {
   const int64_t n_words = (a.n_rows + 63) / 64;
-  const dim3 grid((unsigned)((n_words + kExpWordsPerBlock - 1) / kExpWordsPerBlock));
+  const dim3 grid((unsigned)((n_words + kExpWordsPerBlock - 1) / kExpWordsPerBlock), a.pages ? (unsigned)a.n_pages : 1u);
   if (gather == 0) {
     hipLaunchKernelGGL((fle_select_nullable_kernel<W, 0>), grid, dim3(kThreads), 0, s, enc, n_data, a,
                        reinterpret_cast<uint32_t*>(dense), (const uint32_t*)nullptr, 0u, n_values);

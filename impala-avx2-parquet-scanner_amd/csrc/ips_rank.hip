@@ -413,15 +413,28 @@ ips_status launch_bitmap_compress(const uint64_t* mask, const uint64_t* src, int
 // Per rank tile and per wave quarter: NOT-NULL rows (R), selected rows (S) and selected NOT-NULL
 // rows (RS) in one pass over the two bitmaps; also clears the flag words of the tile (the flags
 // leave fle_select_nullable's compress step through atomics at the segment ends).
+// pages != NULL (ips_chunk_select_nullable): blockIdx.y = page; the page's levels, its selection in the aligned
+// copy (32 words per earlier batch), its tables at rank0; nothing is cleared (the caller cleared the flags).
 template <int ROOT>
 __global__ __launch_bounds__(kRankThreads) void rank3_counts_kernel(
     const u64* __restrict__ root, const u64* __restrict__ sel, int64_t n_rows,
     uint32_t* __restrict__ c_r, uint32_t* __restrict__ c_s, uint32_t* __restrict__ c_rs,
-    u64* __restrict__ zero_out) {
+    u64* __restrict__ zero_out, const ChunkPage* __restrict__ pages) {
   __shared__ uint32_t wave_tot[3][kRankWaves];
   const int lane = lane_id();
   const int wave = wave_id();
-  const int64_t tile = blockIdx.x, tiles = gridDim.x;
+  int64_t tile = blockIdx.x, tiles = gridDim.x;
+  if (pages) {  // wave-uniform
+    const ChunkPage pg = pages[blockIdx.y];
+    n_rows = pg.n_rows;
+    tiles = (((n_rows + 63) / 64) + kRankWordsPerTile - 1) / kRankWordsPerTile;
+    if (tile >= tiles) return;  // (the grid is sized for the largest page)
+    root = reinterpret_cast<const u64*>(pg.levels);
+    sel += (size_t)pg.batch0 * (kRowsPerTile / 64);
+    c_r += pg.rank0;
+    c_s += pg.rank0;
+    c_rs += pg.rank0;
+  }
   const int64_t n_words = (n_rows + 63) / 64;
   const int64_t first = tile * kRankWordsPerTile + wave * kRankWordsPerWave;
   uint32_t cr = 0, cs = 0, crs = 0;
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(kRankThreads) void rank3_counts_kernel(
       cs += __builtin_popcount(b.x) + __builtin_popcount(b.y) + __builtin_popcount(b.z) + __builtin_popcount(b.w);
       crs += __builtin_popcount(ar.x & b.x) + __builtin_popcount(ar.y & b.y) + __builtin_popcount(ar.z & b.z) + __builtin_popcount(ar.w & b.w);
       const u32x4 z = {0u, 0u, 0u, 0u};
-      *reinterpret_cast<u32x4*>(zero_out + w0) = z;
+      if (zero_out) *reinterpret_cast<u32x4*>(zero_out + w0) = z;
     }
   } else {
     for (int r = 0; r < kRankRounds; ++r) {
@@ -451,7 +464,7 @@ __global__ __launch_bounds__(kRankThreads) void rank3_counts_kernel(
           cr += (uint32_t)__builtin_popcountll(m);
           cs += (uint32_t)__builtin_popcountll(sv);
           crs += (uint32_t)__builtin_popcountll(m & sv);
-          zero_out[w0] = 0ull;
+          if (zero_out) zero_out[w0] = 0ull;
         }
       }
     }
@@ -482,9 +495,100 @@ ips_status launch_rank3_counts(int root_kind, const uint64_t* root, const uint64
   const u64* sv = reinterpret_cast<const u64*>(sel);
   u64* z = reinterpret_cast<u64*>(zero_out);
   if (root_kind == kRootLevels1)
-    hipLaunchKernelGGL((rank3_counts_kernel<kRootLevels1>), dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, sv, n_rows, c_r, c_s, c_rs, z);
+    hipLaunchKernelGGL((rank3_counts_kernel<kRootLevels1>), dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, sv, n_rows, c_r, c_s, c_rs, z,
+                       (const ChunkPage*)nullptr);
   else
-    hipLaunchKernelGGL((rank3_counts_kernel<kRootBitmap>), dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, sv, n_rows, c_r, c_s, c_rs, z);
+    hipLaunchKernelGGL((rank3_counts_kernel<kRootBitmap>), dim3((unsigned)tiles), dim3(kRankThreads), 0, s, r, sv, n_rows, c_r, c_s, c_rs, z,
+                       (const ChunkPage*)nullptr);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
+// ---- late materialisation of an OPTIONAL chunk held as a page list (ips_chunk_select_nullable) ----
+// 1. every page's rows of the chunk-wide selection as a bitmap of its own (row 0 of the page at bit 0,
+//    32 words per 2048-row batch slot of the chunk), so that the counting and the selecting kernel read
+//    whole aligned words whatever row the page starts at
+__global__ __launch_bounds__(256) void selection_pages_kernel(const ChunkPage* __restrict__ pages,
+                                                             const u64* __restrict__ sel, int64_t total_words,
+                                                             u64* __restrict__ out) {
+  const ChunkPage pg = pages[blockIdx.y];
+  const int64_t n_words = (pg.n_rows + 63) / 64;
+  u64* dst = out + (size_t)pg.batch0 * (kRowsPerTile / 64);
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_words; j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bit0 = pg.row0 + 64 * j;
+    const int64_t w = bit0 >> 6;
+    const uint32_t sh = (uint32_t)(bit0 & 63);
+    u64 v = sel[w];
+    if (sh) v = (v >> sh) | ((w + 1 < total_words ? sel[w + 1] : 0ull) << (64 - sh));
+    const int64_t valid = pg.n_rows - 64 * j;
+    if (valid < 64) v &= (1ull << valid) - 1ull;
+    dst[j] = v;
+  }
+}
+
+// 3. selected rows / selected NOT-NULL rows in front of every page (exclusive prefix sums over the pages'
+//    tile counts) and both totals: counts[0] = selected rows, counts[1] = values.  One workgroup.
+__global__ __launch_bounds__(256) void selnull_page_bases_kernel(const ChunkPage* __restrict__ pages, int n_pages,
+                                                                const uint32_t* __restrict__ c_s,
+                                                                const uint32_t* __restrict__ c_rs,
+                                                                u64* __restrict__ page_s, u64* __restrict__ page_rs,
+                                                                int64_t* __restrict__ counts) {
+  __shared__ u64 sh_s[256], sh_rs[256];
+  u64 carry_s = 0, carry_rs = 0;
+  for (int p0 = 0; p0 < n_pages; p0 += 256) {
+    const int p = p0 + (int)threadIdx.x;
+    u64 ts = 0, trs = 0;
+    if (p < n_pages) {
+      const ChunkPage pg = pages[p];
+      const int64_t tiles = (((pg.n_rows + 63) / 64) + kRankWordsPerTile - 1) / kRankWordsPerTile;
+      for (int64_t t = 0; t < tiles; ++t) {
+        ts += c_s[pg.rank0 + t];
+        trs += c_rs[pg.rank0 + t];
+      }
+    }
+    sh_s[threadIdx.x] = ts;
+    sh_rs[threadIdx.x] = trs;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {  // inclusive scan
+      const u64 a = (int)threadIdx.x >= d ? sh_s[threadIdx.x - d] : 0ull;
+      const u64 b = (int)threadIdx.x >= d ? sh_rs[threadIdx.x - d] : 0ull;
+      __syncthreads();
+      sh_s[threadIdx.x] += a;
+      sh_rs[threadIdx.x] += b;
+      __syncthreads();
+    }
+    if (p < n_pages) {
+      page_s[p] = carry_s + sh_s[threadIdx.x] - ts;
+      page_rs[p] = carry_rs + sh_rs[threadIdx.x] - trs;
+    }
+    carry_s += sh_s[255];
+    carry_rs += sh_rs[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    counts[0] = (int64_t)carry_s;
+    counts[1] = (int64_t)carry_rs;
+  }
+}
+
+// launches 1-3 of ips_chunk_select_nullable (the fourth, per run of equally wide pages: fle_select_nullable_kernel)
+ips_status launch_selnull_pages_prepare(const ChunkPage* d_pages, int n_pages, int64_t max_rows, const uint64_t* d_sel,
+                                        int64_t chunk_rows, uint64_t* sel_copy, uint32_t* c_r, uint32_t* c_s,
+                                        uint32_t* c_rs, uint64_t* page_s, uint64_t* page_rs, int64_t* counts,
+                                        hipStream_t s) {
+  if (n_pages <= 0) return IPS_OK;
+  const int64_t max_words = (max_rows + 63) / 64;
+  unsigned gx = (unsigned)((max_words + 255) / 256);
+  gx = gx > 64u ? 64u : gx;
+  hipLaunchKernelGGL(selection_pages_kernel, dim3(gx, (unsigned)n_pages), dim3(256), 0, s, d_pages,
+                     reinterpret_cast<const u64*>(d_sel), (chunk_rows + 63) / 64, reinterpret_cast<u64*>(sel_copy));
+  IPS_HIP_TRY(hipGetLastError());
+  const int64_t tiles = rank_tiles(max_rows);
+  hipLaunchKernelGGL((rank3_counts_kernel<kRootLevels1>), dim3((unsigned)tiles, (unsigned)n_pages), dim3(kRankThreads), 0, s,
+                     (const u64*)nullptr, reinterpret_cast<const u64*>(sel_copy), (int64_t)0, c_r, c_s, c_rs, (u64*)nullptr, d_pages);
+  IPS_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(selnull_page_bases_kernel, dim3(1), dim3(256), 0, s, d_pages, n_pages, c_s, c_rs,
+                     reinterpret_cast<u64*>(page_s), reinterpret_cast<u64*>(page_rs), counts);
   IPS_HIP_TRY(hipGetLastError());
   return IPS_OK;
 }

@@ -649,8 +649,9 @@ class HdfsParquetScanner {
   // conjunct list (ips_eval_program_chunks), every slot's late materialisation against the resulting
   // selection (ips_chunk_select: batches cut at the column's own page ends -> ips_batches_compact ->
   // one dense array per slot) and the row-major tuples (ips_assemble_tuples with dense REQUIRED
-  // columns next to the selection's own batch counts).  REQUIRED slots (dictionary, PLAIN); a slot on
-  // an OPTIONAL column makes it return false (those go page by page through AssembleRowsFused).
+  // columns next to the selection's own batch counts).  Slots on OPTIONAL dictionary / FLE columns go through
+  // ips_chunk_select_nullable (values of the selected NOT-NULL rows + NOT-NULL flags, NULL-indicator bits in the
+  // tuples); an OPTIONAL PLAIN slot makes it return false.
   bool AssembleRowsChunks(int tuple_size, const uint8_t* template_tuple, const std::vector<SlotDesc>& slots,
                           std::vector<uint8_t>* tuples, int64_t* num_tuples) {
     if (slots.empty() || slots.size() > IPS_TUPLE_MAX_COLS) return false;
@@ -708,12 +709,42 @@ class HdfsParquetScanner {
       return false;
     std::vector<std::unique_ptr<ips::DeviceBuffer>> keep;
     std::vector<ips_tuple_column> cols(slots.size());
+    int n_optional = 0;
     for (size_t i = 0; i < slots.size(); ++i) {
       BaseColumnReader* r = column_readers_[(size_t)slots[i].col_idx].get();
-      if (r->max_def_level() > 0) return ips::ok(IPS_ERR_UNSUPPORTED, "AssembleRowsChunks: a slot on an OPTIONAL column");
       const ips_chunk* c = chunk_of(slots[i].col_idx);
       if (!c || ips_chunk_num_rows(c) != n) return false;
       const int vw = r->slot_width();
+      if (r->max_def_level() > 0) {
+        // an OPTIONAL column: values of the selected NOT-NULL rows + one NOT-NULL flag per selected row, across
+        // the chunk's pages in four launches (ips_chunk_select_nullable); NULL rows keep the template's bytes and
+        // get their NULL-indicator bit (descriptors.h:60-71)
+        const size_t need = ips_chunk_select_nullable_workspace_bytes(c);
+        if (need == 0) return ips::ok(IPS_ERR_UNSUPPORTED, "AssembleRowsChunks: an OPTIONAL slot needs FLE / dictionary pages");
+        keep.emplace_back(new ips::DeviceBuffer(need + 64));
+        ips::DeviceBuffer& sws = *keep.back();
+        keep.emplace_back(new ips::DeviceBuffer((size_t)std::max<int64_t>(count, 1) * vw + 64));
+        ips::DeviceBuffer& dense = *keep.back();
+        keep.emplace_back(new ips::DeviceBuffer((size_t)((n + 63) / 64 + 2) * 8));
+        ips::DeviceBuffer& flags = *keep.back();
+        ips::DeviceBuffer d_counts(32);
+        int64_t sel_counts[3] = {0, 0, 0};
+        if (!ips::ok(ips_chunk_select_nullable(c, r->dict_handle(), bm.as<uint64_t>(), dense.get(), flags.as<uint64_t>(),
+                                               d_counts.as<int64_t>(), sws.get(), nullptr), "ips_chunk_select_nullable") ||
+            !d_counts.download(sel_counts, 24))
+          return false;
+        if (sel_counts[2]) return ips::ok(IPS_ERR_BAD_INDEX, "AssembleRowsChunks: a dictionary code outside the dictionary");
+        if (sel_counts[0] != count) return ips::ok(IPS_ERR_HIP, "AssembleRowsChunks: a column saw another number of selected rows than the selection holds");
+        memset(&cols[i], 0, sizeof(cols[i]));
+        cols[i].value_width = vw;
+        cols[i].tuple_offset = slots[i].tuple_offset;
+        cols[i].d_dense_values = dense.get();
+        cols[i].d_nonnull_flags = flags.as<uint64_t>();
+        cols[i].null_byte_offset = slots[i].null_byte_offset;
+        cols[i].null_bit_mask = slots[i].null_bit_mask;
+        ++n_optional;
+        continue;
+      }
       const int64_t cb = ips_chunk_num_batches(c);
       keep.emplace_back(new ips::DeviceBuffer((size_t)cb * IPS_BATCH_ROWS * vw));
       ips::DeviceBuffer& values = *keep.back();
@@ -736,7 +767,7 @@ class HdfsParquetScanner {
       cols[i].d_dense_values = dense.get();
     }
     ips::DeviceBuffer d_tuples((size_t)std::max<int64_t>(count, 1) * tuple_size + 64), d_total(16);
-    ips::DeviceBuffer ws(ips_assemble_workspace_bytes(n, 0) + 64);
+    ips::DeviceBuffer ws(ips_assemble_workspace_bytes(n, n_optional) + 64);
     if (!ips::ok(ips_assemble_tuples(cols.data(), (int)cols.size(), counts.as<uint32_t>(), n, tuple_size, template_tuple,
                                      d_tuples.get(), d_total.as<int64_t>(), ws.get(), nullptr), "ips_assemble_tuples"))
       return false;

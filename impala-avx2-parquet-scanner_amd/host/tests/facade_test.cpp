@@ -872,7 +872,38 @@ static void TestAssembleRowsChunks() {
     b.resize((size_t)len);
     return b;
   };
-  const int b0[] = {0, 7001, 30000, n}, b1[] = {0, 20011, n}, b2[] = {0, 33, 4100, 41000, n};
+  // an OPTIONAL int32 dictionary column, ~25 % NULL, four pages ([int32 n_def_bytes][FLE levels][width][codes])
+  std::vector<int32_t> c3(n);
+  std::vector<char> c3_null(n);
+  DictEncoder<int32_t> e3;
+  for (int i = 0; i < n; ++i) {
+    c3_null[i] = (rnd() % 4) == 0;
+    c3[i] = (int32_t)(rnd() % 300) * 7 - 1000;
+    if (!c3_null[i]) e3.Put(c3[i]);
+  }
+  std::vector<uint8_t> d3((size_t)e3.dict_encoded_size() + 8);
+  e3.WriteDict(d3.data());
+  auto page_opt = [&](int lo, int hi) {
+    e3.ClearIndices();
+    std::vector<uint8_t> defbuf((size_t)ips_fle_encoded_bytes(hi - lo, 1));
+    FleEncoder defenc(defbuf.data(), (int)defbuf.size(), 1);
+    for (int i = lo; i < hi; ++i) {
+      defenc.Put(c3_null[(size_t)i] ? 0u : 1u);
+      if (!c3_null[(size_t)i]) e3.Put(c3[(size_t)i]);
+    }
+    const int32_t n_def_bytes = defenc.Flush();
+    std::vector<uint8_t> codes(1 << 19);
+    const int len = e3.WriteData(codes.data(), (int)codes.size());
+    CHECK(len > 0);
+    std::vector<uint8_t> b(4 + (size_t)n_def_bytes + (size_t)len);
+    memcpy(b.data(), &n_def_bytes, 4);
+    memcpy(b.data() + 4, defbuf.data(), (size_t)n_def_bytes);
+    memcpy(b.data() + 4 + n_def_bytes, codes.data(), (size_t)len);
+    return b;
+  };
+  const int b0[] = {0, 7001, 30000, n}, b1[] = {0, 20011, n}, b2[] = {0, 33, 4100, 41000, n}, b3[] = {0, 12345, 12346, 40000, n};
+  std::vector<std::vector<uint8_t>> p3;
+  for (int k = 0; k < 4; ++k) p3.push_back(page_opt(b3[k], b3[k + 1]));
   std::vector<std::vector<uint8_t>> p0, p1;
   for (int k = 0; k < 3; ++k) p0.push_back(page32(b0[k], b0[k + 1]));
   for (int k = 0; k < 2; ++k) p1.push_back(page64(b1[k], b1[k + 1]));
@@ -885,28 +916,37 @@ static void TestAssembleRowsChunks() {
   for (int k = 1; k < 3; ++k) s.AddDataPage(0, p0[(size_t)k].data(), (int)p0[(size_t)k].size(), b0[k + 1] - b0[k]);
   s.AddDataPage(1, p1[1].data(), (int)p1[1].size(), b1[2] - b1[1]);
   for (int k = 1; k < 4; ++k) s.AddDataPage(2, plain.data() + (size_t)b2[k] * 4, (b2[k + 1] - b2[k]) * 4, b2[k + 1] - b2[k]);
+  CHECK(s.AddDictionaryColumn<int32_t>(d3.data(), e3.dict_encoded_size(), p3[0].data(), (int)p3[0].size(), b3[1] - b3[0], 1) == 3);
+  for (int k = 1; k < 4; ++k) s.AddDataPage(3, p3[(size_t)k].data(), (int)p3[(size_t)k].size(), b3[k + 1] - b3[k]);
   s.AddSimplePredicate(s.Own(new AndOperate(s.Own(new GeOperate<int32_t>(0, -100)), s.Own(new LtOperate<int32_t>(0, 120)))));
   s.AddSimplePredicate(s.Own(new LeOperate<int64_t>(1, 30 * 1000003ll)));
-  // tuple: [int64 c1 @0][int32 c0 @8][int32 c2 @12][4 bytes of template @16] = 20 bytes
-  const int ts = 20;
+  // tuple: [int64 c1 @0][int32 c0 @8][int32 c2 @12][int32 c3 (OPTIONAL) @16][NULL indicators @20, bit 0x04 = c3][3 bytes of template] = 24 bytes
+  const int ts = 24;
   uint8_t tmpl[ts];
   for (int i = 0; i < ts; ++i) tmpl[i] = (uint8_t)(0xA0 + i);
-  std::vector<HdfsParquetScanner::SlotDesc> slots = {{1, 0, 0, 0}, {0, 8, 0, 0}, {2, 12, 0, 0}};
+  tmpl[20] = 0x01;  // (another slot's indicator bit, already set in the template: it must survive)
+  std::vector<HdfsParquetScanner::SlotDesc> slots = {{1, 0, 0, 0}, {0, 8, 0, 0}, {2, 12, 0, 0}, {3, 16, 20, 0x04}};
   std::vector<uint8_t> tuples;
   int64_t nt = 0;
   CHECK(s.AssembleRowsChunks(ts, tmpl, slots, &tuples, &nt));
-  int64_t exp = 0, wrong = 0;
+  int64_t exp = 0, wrong = 0, nulls = 0;
   for (int i = 0; i < n; ++i) {
     if (!(c0[(size_t)i] >= -100 && c0[(size_t)i] < 120 && c1[(size_t)i] <= 30 * 1000003ll)) continue;
     if (exp < nt) {
       const uint8_t* t = tuples.data() + (size_t)exp * ts;
-      int64_t v1; int32_t v0, v2;
-      memcpy(&v1, t, 8); memcpy(&v0, t + 8, 4); memcpy(&v2, t + 12, 4);
-      wrong += v1 != c1[(size_t)i] || v0 != c0[(size_t)i] || v2 != c2[(size_t)i] || memcmp(t + 16, tmpl + 16, 4) != 0;
+      int64_t v1; int32_t v0, v2, v3;
+      memcpy(&v1, t, 8); memcpy(&v0, t + 8, 4); memcpy(&v2, t + 12, 4); memcpy(&v3, t + 16, 4);
+      wrong += v1 != c1[(size_t)i] || v0 != c0[(size_t)i] || v2 != c2[(size_t)i] || memcmp(t + 21, tmpl + 21, 3) != 0;
+      if (c3_null[(size_t)i]) {  // the slot keeps the template's bytes, the indicator bit is set
+        wrong += memcmp(t + 16, tmpl + 16, 4) != 0 || t[20] != (0x01 | 0x04);
+        ++nulls;
+      } else {
+        wrong += v3 != c3[(size_t)i] || t[20] != 0x01;
+      }
     }
     ++exp;
   }
-  CHECK(nt == exp && exp > 1000 && wrong == 0);
+  CHECK(nt == exp && exp > 1000 && wrong == 0 && nulls > 100);
   CHECK(ips::sticky_status() == IPS_OK);
 }
 

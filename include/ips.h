@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IPS_VERSION 300 /* 0.3.0: column chunks as page lists (ips_chunk_*), ips_set_program_strategy */
+#define IPS_VERSION 301 /* 0.3.1: column chunks as page lists (ips_chunk_*), ips_set_program_strategy; .1: ips_chunk_select_nullable */
 
 typedef enum {
   IPS_OK = 0,
@@ -523,6 +523,19 @@ ips_status ips_chunk_plain_scan(const ips_chunk* chunk, ips_op op, const void* l
  * of the selection itself (ips_bitmap_batch_counts). */
 ips_status ips_chunk_select(const ips_chunk* chunk, const ips_dict* dict, const uint64_t* d_bitmap,
                             void* d_batch_values, uint32_t* d_batch_counts, ips_stream stream);
+/* The same for an OPTIONAL chunk (FLE values or dictionary codes; flat schema, width-1 levels): ReadValue(skip)
+ * over a whole selection across ReadDataPage boundaries (hdfs-parquet-scanner.cc:1006-1038 + 927-979:
+ * ReadDefinitionLevel says which selected rows are NULL and which data row of ITS page a NOT-NULL one decodes) --
+ * ips_dict_select_nullable with the page loop inside.  d_selection: a bitmap over the chunk's rows.  Outputs as
+ * there: d_dense_values = the values of the selected NOT-NULL rows, densely, in row order (4-byte FLE values, or
+ * dictionary entries of the dictionary's slot size); d_nonnull_flags = one bit per selected row
+ * (ceil(rows / 64) words); d_counts[0] = selected rows, [1] = values, [2] != 0: a selected code lies outside
+ * the dictionary.  Both feed ips_assemble_tuples as an OPTIONAL column.  Four launches whatever the number of
+ * pages (one more per further run of pages of another code width); no synchronisation, nothing allocated. */
+size_t ips_chunk_select_nullable_workspace_bytes(const ips_chunk* chunk);
+ips_status ips_chunk_select_nullable(const ips_chunk* chunk, const ips_dict* dict, const uint64_t* d_selection,
+                                     void* d_dense_values, uint64_t* d_nonnull_flags, int64_t* d_counts,
+                                     void* d_workspace, ips_stream stream);
 
 /* ---- multi-GPU exchange (one process per GPU) ------------------------------------------------ */
 /* The path shards by row stripes (blocks of 64 rows are independent, hdfs-parquet-scanner.cc:

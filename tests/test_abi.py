@@ -21,7 +21,7 @@ def test_library_exports_every_symbol(ips):
     lib = ips.capi.lib()
     for name in header_functions():
         assert hasattr(lib, name), name
-    assert lib.ips_version() == 300
+    assert lib.ips_version() == 301
 
 
 def test_pure_host_entry_points(ips):

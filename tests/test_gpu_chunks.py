@@ -419,3 +419,62 @@ def test_chunk_program_one_pass_over_common_pages(capi, O, seed, request):
             assert int(got_words[-1]) >> (n % 64) == 0, "bits behind the last row are zero"
     for ch in chunks:
         ch.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_chunk_select_nullable_pages(capi, O, seed):
+    """ips_chunk_select_nullable: late materialisation of an OPTIONAL column across its pages
+    (ReadValue(skip) + ReadDefinitionLevel over ReadDataPage boundaries, hdfs-parquet-scanner.cc:927-979, 1006-1038):
+    dense values of the selected NOT-NULL rows in row order, one NOT-NULL flag per selected row, both counts.
+    Pages of every awkward size incl. empty and all-NULL ones, page starts inside selection words, code widths
+    that grow along the chunk (several runs), FLE values and dictionary entries of 4 and 8 bytes; against the
+    row model."""
+    rng = np.random.default_rng(1200 + seed)
+    n = int(rng.choice([1, 77, 5000, 70001, 400009]))
+    sizes = [RAGGED, [2048, 4096], [1, 5, 31, 33, 64], [70001, 10000, 0], [65536 * 4 + 3, 100], RAGGED][seed]
+    page_rows = cuts(rng, n, sizes)
+    null_frac = [0.2, 0.0, 0.5, 0.9, 0.1, 1.0][seed]
+    is_set = rng.random(n) >= null_frac
+    use_dict = seed % 3  # 0: FLE values, 1: int32 dictionary, 2: int64 dictionary
+    if use_dict:
+        t = capi.T_INT32 if use_dict == 1 else capi.T_INT64
+        pool = np.sort(rng.choice(np.arange(-10 ** 6, 10 ** 6), 300, replace=False)).astype(O.NP_TYPES[t])
+        codes = rng.integers(0, len(pool), n).astype(np.uint32)
+        row_vals = pool[codes]
+        d = capi.Dict(O.plain_encode(pool, t), t)
+        widths = [9, 9, 10]  # (the writer's width grows with the dictionary; the codes fit all of them)
+    else:
+        codes = rng.integers(0, 1 << 7, n).astype(np.uint32)
+        row_vals = codes
+        d = None
+        widths = [7, 7, 11]
+    pages, pos = [], 0
+    for i, m in enumerate(page_rows):
+        w = widths[min(i * 3 // max(len(page_rows), 1), 2)]
+        if m == 0:
+            pages.append((None, 0, w, torch.zeros(2, dtype=torch.int64, device="cuda"), 0))
+            continue
+        s = is_set[pos:pos + m]
+        k = int(s.sum())
+        defs = O.fle_encode(s.astype(np.uint32), 1)
+        enc = O.fle_encode(codes[pos:pos + m][s], w) if k else np.zeros(2, np.uint64)
+        pages.append((dev_words(enc), m, w, dev_words(defs), k))
+        pos += m
+    ch = capi.Chunk(pages, max_def_level=1)
+    for density in (0.1, 1.0, 0.0, 0.6):
+        sel = rng.random(n) < density
+        if density == 1.0:
+            sel[:] = True
+        bm = torch.from_numpy(np.concatenate([pack(sel), np.zeros(2, np.uint64)]).view(np.int64)).cuda()
+        dense, flags, n_sel, n_val, bad = ch.select_nullable(bm, d)
+        assert bad == 0
+        assert n_sel == int(sel.sum()) and n_val == int((sel & is_set).sum()), (seed, density, n)
+        exp = row_vals[sel & is_set]
+        got = dense.cpu().numpy()
+        if not use_dict:
+            got = got.view(np.uint32)
+        assert np.array_equal(got, exp), (seed, density, n, page_rows[:6])
+        assert np.array_equal(bits_of(words(flags), n_sel), is_set[sel]), (seed, density, n)
+    ch.close()
+    if d:
+        d.close()

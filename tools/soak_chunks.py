@@ -118,6 +118,7 @@ def plain_col(n):
 
 
 bad = 0
+optional_sets = {}
 for it in range(ITERS):
     n = int(rng.choice([1, 70, 3000, 2048 * 7, int(rng.integers(1, 250000))]))
     cols = []
@@ -129,6 +130,8 @@ for it in range(ITERS):
         else:
             ch, ex, vals, is_set, w = fle_col(n, kind == 1)
             cols.append(("fle", ch, ex, vals, w))
+            if kind == 1:
+                optional_sets[id(ch)] = is_set
     leaves = []
     for _ in range(int(rng.integers(1, 6))):
         ci = int(rng.integers(0, len(cols)))
@@ -173,6 +176,20 @@ for it in range(ITERS):
             elif not np.array_equal(ch.compact(bv, cnt).cpu().numpy().view(np.uint32), vals[e]):
                 bad += 1; print("scan values mismatch", it, n)
             break
+    # late materialisation of the OPTIONAL FLE columns across their pages (ips_chunk_select_nullable)
+    for kind, ch, ex, vals, extra in cols:
+        if kind == "fle" and id(ch) in optional_sets:
+            is_set = optional_sets[id(ch)]
+            sel = rng.random(n) < float(rng.choice([0.02, 0.3, 1.0]))
+            bm = torch.from_numpy(np.concatenate([pack(sel), np.zeros(2, np.uint64)]).view(np.int64)).cuda()
+            dense, flags, n_sel, n_val, bad_idx = ch.select_nullable(bm)
+            if n_sel != int(sel.sum()) or n_val != int((sel & is_set).sum()) or bad_idx:
+                bad += 1; print("select_nullable counts mismatch", it, n)
+            elif not np.array_equal(dense.cpu().numpy().view(np.uint32), vals[sel & is_set]):
+                bad += 1; print("select_nullable values mismatch", it, n)
+            elif not np.array_equal(bits(words(flags), n_sel), is_set[sel]):
+                bad += 1; print("select_nullable flags mismatch", it, n)
+    optional_sets.clear()
     for c in cols:
         c[1].close()
 print("soak done, mismatches:", bad)
