@@ -336,7 +336,8 @@ static ips_status chain_layout(ChainArgsW& a, const void* const* enc, int64_t n_
     const int w = a.ops[i].w;
     maxw = w > maxw ? w : maxw;
     const int64_t bytes = n_blocks * w * 8;
-    if (bytes >= 0xFFFFFFF0ll) return IPS_ERR_UNSUPPORTED;
+    // (32-bit offsets: the last sub-tile's chunks beyond the column must stay below 2^32 to be range-checked away)
+    if (bytes >= 0xFFFF0000ll) return IPS_ERR_UNSUPPORTED;
     a.ops[i].img_dw = img;
     for (int k = 0; k < 16; ++k) {
       a.ops[i].m1[k] = ((a.ops[i].c1 >> k) & 1u) ? ~0u : 0u;
