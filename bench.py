@@ -255,6 +255,36 @@ def leg_nullable(capi, dev, n):
     out.append(rec("OPTIONAL FLE w=12 column, 10% NULL: late materialisation of the leaf's selection "
                    "(levels + selection + data -> dense values + NOT-NULL flags, 2 launches)", n, byts2, tmed, tmin,
                    bool(ok2), selected_rows=n_sel))
+    t_contig = tmed
+    # the same over the column as a LIST OF PAGES (separate buffers per page, levels and data blocks restart at
+    # every page): ips_chunk_select_nullable, 4 launches whatever the number of pages
+    for label, rows in (("256 pages of 2^20 rows", 1 << 20), ("257 pages of 2^20 - 37 rows", (1 << 20) - 37)):
+        pages, pos, dpos = [], 0, 0
+        while pos < n:
+            m = min(rows, n - pos)
+            s_p = is_set[pos:pos + m]
+            k_p = int(s_p.sum().item())
+            pages.append((capi.fle_encode(vals[dpos:dpos + k_p].clone(), 12) if k_p else None, m, 12,
+                          capi.fle_encode(s_p.to(torch.int32), 1), k_p))
+            pos += m
+            dpos += k_p
+        chunk = capi.Chunk(pages, max_def_level=1)
+        lib.ips_chunk_select_nullable_workspace_bytes.restype = C.c_size_t
+        lib.ips_chunk_select_nullable_workspace_bytes.argtypes = [C.c_void_p]
+        ws3 = torch.empty(int(lib.ips_chunk_select_nullable_workspace_bytes(chunk.h)) + 16, dtype=torch.uint8, device=dev)
+        dense_p = torch.empty(n_sel + 64, dtype=torch.int32, device=dev)
+        flags_p = torch.empty((n + 63) // 64, dtype=torch.int64, device=dev)
+        cnts_p = torch.zeros(3, dtype=torch.int64, device=dev)
+
+        def mat_pages():
+            capi._ck(lib.ips_chunk_select_nullable(chunk.h, None, P(bm), P(dense_p), P(flags_p), P(cnts_p), P(ws3), stream))
+        tmed, tmin = time_launches(mat_pages)
+        ok3 = (cnts_p.cpu().tolist() == [n_sel, n_sel, 0] and torch.equal(dense_p[:n_sel], dense[:n_sel])
+               and torch.equal(flags_p[:(n_sel + 63) // 64], flags[:(n_sel + 63) // 64]))
+        out.append(rec(f"OPTIONAL FLE w=12 column, 10% NULL: late materialisation over a page list, {label} (4 launches)",
+                       n, byts2, tmed, tmin, bool(ok3), vs_contiguous=round(tmed / t_contig, 3)))
+        chunk.close()
+        del pages, ws3, dense_p, flags_p
     return out
 
 
