@@ -62,6 +62,45 @@ struct ChainPagedArgsW {
   ChainPagesArgs pg;
 };
 
+// The chain over column chunks whose pages end at DIFFERENT rows (ips_chain.hip: segments).
+constexpr int kChainSegRunDwords = 62;                      // bitmap dwords per stripe
+constexpr int kChainSegRows = kChainSegRunDwords * 32;      // 1984 rows per stripe
+constexpr int kChainSegMaxBounds = 4096;                    // page starts of all operands together (LDS of the merge)
+struct ChainSegSlot {
+  const uint64_t* base;   // the operand's page data, from the block that holds the segment's first row on
+  int64_t blocks;         // blocks the page holds from there on
+};
+struct ChainSegArgs {
+  const void* slot_pages[kChainWMaxSlots];  // per load slot: its operand's ChunkPage table (whole chunk)
+  const void* op_pages[kChainWMaxOps];      // per operand
+  int32_t op_n_pages[kChainWMaxOps];
+  int32_t slot_op[kChainWMaxSlots];         // the slot's operand
+  int32_t op_w[kChainWMaxOps + 2];          // the operands' bit widths
+  const void* seg_pages;                    // ChunkPage per segment: row0, n_rows, batch0 = first edge slot, flags
+  // per segment, filled by chain_segments_kernel so that a wave of the chain needs ONE round of loads to start:
+  const ChainSegSlot* seg_slots;            // [segment][8]: first block of the segment in the operand's page, per operand
+  const uint32_t* seg_bits;                 // [segment][8]: rows of that block in front of the segment (0..63), per operand
+  // the chain's workgroups (4 stripes each) dealt to the segments: no workgroup without a segment
+  const uint32_t* wg_seg;                   // [workgroup]: its segment
+  const uint32_t* seg_wg0;                  // [segment]: its first workgroup
+  const uint32_t* n_wgs;                    // workgroups with work
+  int64_t chunk_rows;
+  uint32_t* edges;
+  int32_t n_bounds;                         // segments (page starts of all operands, ties kept: some are empty)
+  int32_t reserved;
+};
+struct ChainSegmentedArgsW {
+  ChainArgsW chain;
+  ChainSegArgs sg;
+};
+// bytes of workspace the segmented chain needs for n_bounds page starts over chunk_rows rows
+size_t chain_segments_workspace_bytes(int n_bounds, int64_t chunk_rows);
+// sa.chain.ops[0..n_ops) filled by the caller; op_pages / op_n_pages: every operand's device page table; max_rows: rows
+// of the largest page of any operand; workspace of chain_segments_workspace_bytes() bytes.  Three launches + the fix-up.
+ips_status launch_chain_w_segments(ChainSegmentedArgsW& sa, const void* const* op_pages, const int* op_n_pages,
+                                   int64_t max_rows, int64_t chunk_rows, uint32_t* bitmap32, void* workspace,
+                                   hipStream_t s);
+
 // IPS_ERR_UNSUPPORTED: the chain does not fit the kernel (more than kChainWMaxSlots load slots, a
 // column of 4 GiB or more) -- the caller falls back to the per-operand plan
 ips_status launch_chain_w(ChainArgsW& a, const void* const* enc, int64_t n_rows, uint32_t* bitmap32, hipStream_t s);

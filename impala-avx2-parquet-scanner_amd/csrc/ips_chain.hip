@@ -276,6 +276,221 @@ __global__ __launch_bounds__(kThreads, chain_min_waves(LTOT, MAXW)) void fle_cha
   chain_body<LTOT, MAXW, true>((ChainArgsK)pa, pa, 0, bitmap32, lds_all);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The chain over chunks whose pages end at DIFFERENT rows -- the usual case: every column writer cuts
+// its pages by its own byte count, and EvalSimplePredicates cuts its batches at every column's page
+// end (hdfs-parquet-scanner.cc:1837-1855).  The page starts of all operands cut the chunk's rows into
+// SEGMENTS inside which every operand stays in one page.  A segment starts at an arbitrary row r of
+// an operand's page: block r / 64, bit r % 64.  A stripe is therefore 62 bitmap dwords = 1984 rows:
+// whatever the bit offset (0..63), the 32 blocks from the stripe's first block on hold all of its rows,
+// so every operand still takes ONE ordinary 32-block sub-tile per stripe (consecutive stripes re-read one
+// block), stripes stay independent -- one per wave, any order -- and the operand's result dwords are
+// shifted into place with two DPP moves and a funnel shift.  The stripe's 62 dwords leave through the
+// segment's window into the chunk-wide bitmap (a segment is a "page" of the bitmap: ips_chunk_device.h;
+// segments that start inside a bitmap dword use edge slots + the fix-up launch).
+// chain_segments_kernel (one workgroup) merges the page starts on the device, so the call stays
+// asynchronous and allocation-free: ranks by binary search in an LDS copy of the starts; it also deals the
+// chain's workgroups (four stripes each) to the segments, so that no workgroup is without work.
+// Measured on the Q6 shape (pages of 2^20 / 2^20 - 37 / 700 001 rows: 2002 segments of 37 .. 700 001 rows):
+// the chain kernel 352 us + the merge 25-49 us + the fix-up 9 us = 400-426 us against 417 us for the three
+// per-operand launches with their fix-ups -- a tie, which is why only IPS_PROGRAM_ONE_PASS selects it.  The wave
+// of a stripe sits behind three dependent rounds of loads (its segment's number, the segment's tables, the data;
+// the contiguous chain: one, the chain over common pages: two) and the 6.4 KiB of plane images per wave
+// bound the resident waves at six per SIMD, so every extra round costs ~0.85 us x 303 000 stripes / 6144 waves.
+// With blockIdx.y = segment instead of the workgroup map 41 % of the wave slots stayed idle (segments of 1 to
+// 353 stripes): the same 352 us.
+// ---------------------------------------------------------------------------------------------
+typedef const ChainSegmentedArgsW __attribute__((address_space(4))) * ChainSegArgsK;
+
+// upper bound of the chain's workgroups (four stripes each): every segment wastes less than one
+static int64_t chain_seg_max_wgs(int n_bounds, int64_t chunk_rows) {
+  return (chunk_rows / kChainSegRows + n_bounds) / kWavesPerBlock + n_bounds + 1;
+}
+
+__global__ __launch_bounds__(1024) void chain_segments_kernel(ChainSegArgs sg, int n_ops, ChunkPage* __restrict__ seg_pages,
+                                                              ChainSegSlot* __restrict__ seg_slots,
+                                                              uint32_t* __restrict__ seg_bits, uint32_t* __restrict__ wg_seg,
+                                                              uint32_t* __restrict__ seg_wg0, uint32_t* __restrict__ n_wgs) {
+  __shared__ int64_t starts[kChainSegMaxBounds];   // operand after operand
+  __shared__ int64_t merged[kChainSegMaxBounds];
+  int first[kChainWMaxOps + 1];
+  first[0] = 0;
+#pragma unroll
+  for (int i = 0; i < kChainWMaxOps; ++i) first[i + 1] = first[i] + (i < n_ops ? sg.op_n_pages[i] : 0);
+  const int n_bounds = first[kChainWMaxOps];
+#pragma unroll
+  for (int i = 0; i < kChainWMaxOps; ++i) {
+    if (i < n_ops) {
+      const ChunkPage* pages = reinterpret_cast<const ChunkPage*>(sg.op_pages[i]);
+      for (int p = threadIdx.x; p < sg.op_n_pages[i]; p += blockDim.x) starts[first[i] + p] = pages[p].row0;
+    }
+  }
+  __syncthreads();
+  // entries of operand j's list below x (strict) or not above it
+  auto count = [&](int j, int64_t x, bool or_equal) -> int {
+    int lo = first[j], hi = first[j + 1];
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const int64_t v = starts[mid];
+      if (v < x || (or_equal && v == x)) lo = mid + 1; else hi = mid;
+    }
+    return lo - first[j];
+  };
+  for (int g = threadIdx.x; g < n_bounds; g += blockDim.x) {
+    int op = 0;
+#pragma unroll
+    for (int i = 1; i < kChainWMaxOps; ++i) op += (i < n_ops && g >= first[i]) ? 1 : 0;
+    const int64_t x = starts[g];
+    int rank = g - first[op];  // (an operand's own starts are strictly increasing)
+#pragma unroll
+    for (int j = 0; j < kChainWMaxOps; ++j)
+      if (j < n_ops && j != op) rank += count(j, x, j < op);  // ties: the lower operand first
+    merged[rank] = x;
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < n_bounds; r += blockDim.x) {
+    const int64_t start = merged[r];
+    const int64_t end = r + 1 < n_bounds ? merged[r + 1] : sg.chunk_rows;
+    ChunkPage sp;
+    sp.data = nullptr;
+    sp.levels = nullptr;
+    sp.n_rows = end - start;
+    sp.n_data = end - start;
+    sp.row0 = start;
+    sp.batch0 = (uint32_t)(start / kChainSegRows + r);  // first edge slot: unique and increasing over the segments
+    sp.flags = r + 1 == n_bounds ? kPageLast : 0u;
+    sp.rank0 = 0u;
+    sp.reserved = 0u;
+    seg_pages[r] = sp;
+    // where the segment starts inside every operand's page
+#pragma unroll
+    for (int j = 0; j < kChainWMaxOps; ++j) {
+      ChainSegSlot sl;
+      sl.base = nullptr;
+      sl.blocks = 0;
+      uint32_t bit = 0u;
+      if (j < n_ops) {
+        const ChunkPage* pg = reinterpret_cast<const ChunkPage*>(sg.op_pages[j]) + (count(j, start, true) - 1);
+        const int64_t in_page = start - pg->row0;
+        const int64_t b0 = in_page >> 6;
+        sl.base = pg->data + b0 * sg.op_w[j];
+        sl.blocks = (pg->n_rows + 63) / 64 - b0;
+        bit = (uint32_t)(in_page & 63);
+      }
+      seg_slots[(size_t)r * 8 + j] = sl;
+      seg_bits[r * 8 + j] = bit;
+    }
+  }
+  // the chain's workgroups: ceil(stripes / 4) per segment, dealt in segment order (exclusive prefix sums over
+  // the segments: four consecutive segments per thread, then a scan of the 1024 partial sums)
+  __syncthreads();  // (the starts are not needed any more: their array holds the scan)
+  uint32_t* scan = reinterpret_cast<uint32_t*>(starts);
+  auto wgs_of = [&](int r) -> uint32_t {
+    if (r >= n_bounds) return 0u;
+    const int64_t rows = (r + 1 < n_bounds ? merged[r + 1] : sg.chunk_rows) - merged[r];
+    const int64_t stripes = (rows + kChainSegRows - 1) / kChainSegRows;
+    return (uint32_t)((stripes + kWavesPerBlock - 1) / kWavesPerBlock);
+  };
+  const int r0 = (int)threadIdx.x * 4;
+  const uint32_t c0 = wgs_of(r0), c1 = wgs_of(r0 + 1), c2 = wgs_of(r0 + 2), c3 = wgs_of(r0 + 3);
+  scan[threadIdx.x] = c0 + c1 + c2 + c3;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const uint32_t add = (int)threadIdx.x >= d ? scan[threadIdx.x - d] : 0u;
+    __syncthreads();
+    scan[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t at = scan[threadIdx.x] - (c0 + c1 + c2 + c3);  // workgroups in front of segment r0
+  const uint32_t cnt[4] = {c0, c1, c2, c3};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (r0 + k < n_bounds) {
+      seg_wg0[r0 + k] = at;
+      for (uint32_t g = 0; g < cnt[k]; ++g) wg_seg[at + g] = (uint32_t)(r0 + k);
+      at += cnt[k];
+    }
+  }
+  if (threadIdx.x == 1023) *n_wgs = scan[1023];
+}
+
+template <int LTOT, int MAXW>
+__global__ __launch_bounds__(kThreads, chain_min_waves(LTOT, MAXW)) void fle_chain_w_segments_kernel(
+    ChainSegmentedArgsW a_by_value, uint32_t* __restrict__ bitmap32) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
+  (void)a_by_value;
+  const ChainSegArgsK sa = (ChainSegArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+  const ChainArgsK a = (ChainArgsK)sa;
+  if (blockIdx.x >= *sa->sg.n_wgs) return;  // (the grid is the host's upper bound)
+  const uint32_t si = sa->sg.wg_seg[blockIdx.x];
+  const ChunkPage seg = reinterpret_cast<const ChunkPage*>(sa->sg.seg_pages)[si];
+  const int lane = lane_id();
+  const int wave = wave_id();
+  // one stripe per wave, four consecutive ones per workgroup
+  const int64_t t = (int64_t)(blockIdx.x - sa->sg.seg_wg0[si]) * kWavesPerBlock + wave;
+  if (t * kChainSegRows >= seg.n_rows) return;
+  uint32_t* lds32 = lds_all + wave * a->image_dwords;
+  const BitmapWindow win = bitmap_window(bitmap32, seg, sa->sg.chunk_rows, nullptr, sa->sg.edges);
+  const int n_ops = a->n_ops;
+  const uint32_t lane_byte = (uint32_t)lane * 16u;
+  // per operand: the first block of the segment in its page, the blocks the page holds from there on and the rows
+  // of that block in front of the segment (prepared by chain_segments_kernel: nothing here depends on another load
+  // but the segment's number)
+  const ChainSegSlot* slots_of_seg = sa->sg.seg_slots + (size_t)si * 8;
+  const uint32_t* bits_of_seg = sa->sg.seg_bits + (size_t)si * 8;
+  uint32_t op_bit[kChainWMaxOps];
+#pragma unroll
+  for (int i = 0; i < kChainWMaxOps; ++i) op_bit[i] = bits_of_seg[i];
+  u32x4 r[LTOT];
+  // slot i: the 32 blocks from block 31 t of the segment on (the page's bytes bound the loads)
+#pragma unroll
+  for (int i = 0; i < LTOT; ++i) {
+    const uint32_t first = a->slots[i].first_byte, tile_bytes = a->slots[i].tile_bytes;
+    const uint32_t w = tile_bytes >> 8;
+    const ChainSegSlot sl = slots_of_seg[sa->sg.slot_op[i]];
+    int64_t left = (sl.blocks - 31 * t) * (int64_t)w * 8;
+    left = left < 0 ? 0 : (left > (int64_t)tile_bytes ? (int64_t)tile_bytes : left);
+    const uint32_t in_tile = first + lane_byte;
+    r[i] = buffer_load16<true>(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(sl.base + 31 * t * (int64_t)w), 0,
+                                                                 tile_bytes ? (int)left : 0, kBufferRsrcDword3),
+                               in_tile < tile_bytes ? in_tile : 0xFFFFFFF0u);
+  }
+#pragma unroll
+  for (int i = 0; i < LTOT; ++i) {
+    const uint32_t first = a->slots[i].first_byte, tile_bytes = a->slots[i].tile_bytes;
+    const uint32_t in_tile = first + lane_byte;
+    if (in_tile < tile_bytes) {
+      const uint32_t w = tile_bytes >> 8;
+      const uint32_t wi = in_tile >> 3;
+      const uint32_t blk = __umulhi(wi, a->slots[i].inv_w);
+      uint32_t* dst = lds32 + a->slots[i].img_dw + 2 * (blk * (w | 1u) + (wi - blk * w));
+      const u32x2 lo = {r[i].x, r[i].y}, hi = {r[i].z, r[i].w};
+      *reinterpret_cast<u32x2*>(dst) = lo;
+      *reinterpret_cast<u32x2*>(dst + 2) = hi;
+    }
+  }
+  wave_lds_fence();
+  uint32_t acc = 0u;
+#pragma unroll 1
+  for (int i = 0; i < n_ops; ++i) {
+    const ChainStep o = chain_step(a, i);
+    uint32_t sel = 0u;
+    width_switch<MAXW>(o.w, [&](auto W) { sel = chain_eval<decltype(W)::value>(lds32 + o.img_dw, lane, o); });
+    // rows 32 l .. 32 l + 31 of the sub-tile -> rows of the stripe: the segment starts 'bit' rows into the block
+    uint32_t bit = op_bit[0];
+#pragma unroll
+    for (int j = 1; j < kChainWMaxOps; ++j) bit = i == j ? op_bit[j] : bit;  // (wave-uniform selects)
+    uint32_t lo = bitrev32(sel);
+    if (bit & 32u) lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x130, 0xF, 0xF, true);  // wave_shl:1
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x130, 0xF, 0xF, true);
+    sel = __builtin_amdgcn_alignbit(hi, lo, bit & 31u);
+    acc = o.combine == 0 ? sel : o.combine == 1 ? (acc & sel) : (acc | sel);
+  }
+  WindowCarry carry;
+  window_emit(win, carry, t * kChainSegRunDwords + lane, acc, 0, kChainSegRunDwords - 1, nullptr, t);
+  window_flush(win, carry, 0);
+}
+
 // resident workgroups per CU of a kernel with 'lds' bytes of dynamic image (not known to the occupancy cache
 // of grid_for_tiles)
 static int chain_resident(const void* kern, size_t lds) {
@@ -369,6 +584,16 @@ static ips_status chain_layout(ChainArgsW& a, const void* const* enc, int64_t n_
   return IPS_OK;
 }
 
+template <int LTOT, int MAXW>
+static ips_status launch_chain_w_segments_class(const ChainSegmentedArgsW& sa, int64_t chunk_rows, uint32_t* bitmap32,
+                                                hipStream_t s) {
+  auto kern = fle_chain_w_segments_kernel<LTOT, MAXW>;
+  const size_t lds = (size_t)kWavesPerBlock * sa.chain.image_dwords * 4;
+  hipLaunchKernelGGL(kern, dim3((unsigned)chain_seg_max_wgs(sa.sg.n_bounds, chunk_rows)), dim3(kThreads), lds, s, sa, bitmap32);
+  IPS_HIP_TRY(hipGetLastError());
+  return IPS_OK;
+}
+
 #define IPS_CHAIN_DISPATCH(FN, SLOTS, MAXW, ...)                                              \
   do {                                                                                        \
     if ((SLOTS) <= 2) return (MAXW) <= 16 ? FN<2, 16>(__VA_ARGS__) : FN<2, 32>(__VA_ARGS__);   \
@@ -395,6 +620,77 @@ ips_status launch_chain_w_pages(ChainPagedArgsW& pa, const void* const* op_pages
   for (int i = 0; i < kChainWMaxSlots; ++i)
     pa.pg.slot_pages[i] = op_pages[i < pa.chain.n_slots ? (int)pa.chain.slots[i].rsrc[0] : 0];
   IPS_CHAIN_DISPATCH(launch_chain_w_pages_class, pa.chain.n_slots, maxw, pa, n_pages, max_rows, bitmap32, s);
+}
+
+namespace {
+struct ChainSegWs {
+  ChunkPage* seg_pages;
+  ChainSegSlot* seg_slots;
+  uint32_t* seg_bits;
+  uint32_t* wg_seg;
+  uint32_t* seg_wg0;
+  uint32_t* n_wgs;
+  uint32_t* edges;
+  size_t total;
+};
+size_t seg_align(size_t x) { return (x + 255) & ~(size_t)255; }
+ChainSegWs chain_seg_ws(void* base, int n_bounds, int64_t chunk_rows) {
+  uint8_t* p = reinterpret_cast<uint8_t*>(base);
+  ChainSegWs w;
+  size_t off = 0;
+  w.seg_pages = reinterpret_cast<ChunkPage*>(p + off); off += seg_align((size_t)n_bounds * sizeof(ChunkPage));
+  w.seg_slots = reinterpret_cast<ChainSegSlot*>(p + off); off += seg_align((size_t)n_bounds * 8 * sizeof(ChainSegSlot));
+  w.seg_bits = reinterpret_cast<uint32_t*>(p + off); off += seg_align((size_t)n_bounds * 8 * 4);
+  w.wg_seg = reinterpret_cast<uint32_t*>(p + off); off += seg_align((size_t)chain_seg_max_wgs(n_bounds, chunk_rows) * 4);
+  w.seg_wg0 = reinterpret_cast<uint32_t*>(p + off); off += seg_align((size_t)n_bounds * 4);
+  w.n_wgs = reinterpret_cast<uint32_t*>(p + off); off += 256;
+  // edge slots: 4 dwords per stripe; slot of a stripe = first row / 1984 + segment index (+ stripe in the segment)
+  w.edges = reinterpret_cast<uint32_t*>(p + off); off += seg_align(((size_t)(chunk_rows / kChainSegRows) + (size_t)n_bounds + 4) * 16);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+size_t chain_segments_workspace_bytes(int n_bounds, int64_t chunk_rows) {
+  return chain_seg_ws(nullptr, n_bounds, chunk_rows).total;
+}
+
+ips_status launch_chain_w_segments(ChainSegmentedArgsW& sa, const void* const* op_pages, const int* op_n_pages,
+                                   int64_t max_rows, int64_t chunk_rows, uint32_t* bitmap32, void* workspace,
+                                   hipStream_t s) {
+  int maxw = 0, n_bounds = 0;
+  const ips_status st = chain_layout(sa.chain, nullptr, (max_rows + 63) / 64 + 64, &maxw);
+  if (st != IPS_OK) return st;
+  for (int i = 0; i < sa.chain.n_ops; ++i) n_bounds += op_n_pages[i];
+  if (n_bounds <= 0 || n_bounds > kChainSegMaxBounds) return IPS_ERR_UNSUPPORTED;
+  const ChainSegWs w = chain_seg_ws(workspace, n_bounds, chunk_rows);
+  for (int i = 0; i < kChainWMaxOps; ++i) {
+    sa.sg.op_pages[i] = op_pages[i < sa.chain.n_ops ? i : 0];
+    sa.sg.op_n_pages[i] = i < sa.chain.n_ops ? op_n_pages[i] : 0;
+    sa.sg.op_w[i] = i < sa.chain.n_ops ? sa.chain.ops[i].w : 0;
+  }
+  for (int i = 0; i < kChainWMaxSlots; ++i) {
+    sa.sg.slot_op[i] = i < sa.chain.n_slots ? (int)sa.chain.slots[i].rsrc[0] : 0;
+    sa.sg.slot_pages[i] = op_pages[sa.sg.slot_op[i]];
+  }
+  sa.sg.seg_pages = w.seg_pages;
+  sa.sg.seg_slots = w.seg_slots;
+  sa.sg.seg_bits = w.seg_bits;
+  sa.sg.wg_seg = w.wg_seg;
+  sa.sg.seg_wg0 = w.seg_wg0;
+  sa.sg.n_wgs = w.n_wgs;
+  sa.sg.chunk_rows = chunk_rows;
+  sa.sg.edges = w.edges;
+  sa.sg.n_bounds = n_bounds;
+  hipLaunchKernelGGL(chain_segments_kernel, dim3(1), dim3(1024), 0, s, sa.sg, sa.chain.n_ops, w.seg_pages, w.seg_slots,
+                     w.seg_bits, w.wg_seg, w.seg_wg0, w.n_wgs);
+  IPS_HIP_TRY(hipGetLastError());
+  auto launch = [&]() -> ips_status {
+    IPS_CHAIN_DISPATCH(launch_chain_w_segments_class, sa.chain.n_slots, maxw, sa, chunk_rows, bitmap32, s);
+  };
+  const ips_status st2 = launch();
+  if (st2 != IPS_OK) return st2;
+  return launch_window_fixup(w.seg_pages, n_bounds, max_rows, chunk_rows, bitmap32, w.edges, 0, s, kChainSegRunDwords);
 }
 
 }  // namespace ips

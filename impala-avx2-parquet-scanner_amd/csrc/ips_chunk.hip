@@ -68,13 +68,16 @@ ips_status launch_fle_scan_chunk(int w, int mode, int gather, const ChunkPage* d
 // low part of sub-tile t, which the paged kernel left in the edge slots.  Inside a page such a dword is
 // complete (plain store / read-modify-write); at the page's two ends it is shared with the
 // neighbouring pages and merged atomically -- two atomics per page.
+// run_dwords: dwords per run of the kernel that filled the slots (64: sub-tiles of 2048 rows; 62: the segmented chain)
 __global__ __launch_bounds__(256) void window_fixup_kernel(const ChunkPage* __restrict__ pages, int64_t chunk_rows,
                                                            uint32_t* __restrict__ bitmap32,
-                                                           const uint32_t* __restrict__ edges, int combine) {
+                                                           const uint32_t* __restrict__ edges, int combine, int run_dwords) {
   const ChunkPage pg = pages[blockIdx.y];
+  if (pg.n_rows <= 0) return;  // (an empty segment of the segmented chain)
   const BitmapWindow w = bitmap_window(bitmap32, pg, chunk_rows);
   if (w.shift == 0u) return;
-  const int64_t tiles = (pg.n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int64_t run_rows = (int64_t)run_dwords * 32;
+  const int64_t tiles = (pg.n_rows + run_rows - 1) / run_rows;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t > tiles) return;
   const uint32_t s = w.shift, r = 32u - s;
@@ -86,13 +89,13 @@ __global__ __launch_bounds__(256) void window_fixup_kernel(const ChunkPage* __re
   uint32_t val = 0u, mask = 0u;
   if (t < tiles) {
     val |= e[4 * t];
-    mask |= rows_mask(64 * t) << s;
+    mask |= rows_mask(run_dwords * t) << s;
   }
   if (t > 0) {
     val |= e[4 * (t - 1) + 1];
-    mask |= rows_mask(64 * t - 1) >> r;
+    mask |= rows_mask(run_dwords * t - 1) >> r;
   }
-  const int64_t d = 64 * t;
+  const int64_t d = run_dwords * t;
   const bool tail = w.own_tail && d == w.tail_dword && mask != 0u;
   if (tail) mask |= w.tail_mask;
   window_put(w.base + d, val & mask, mask, combine, 0u);
@@ -100,11 +103,11 @@ __global__ __launch_bounds__(256) void window_fixup_kernel(const ChunkPage* __re
 }
 
 ips_status launch_window_fixup(const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
-                               uint32_t* bitmap32, const uint32_t* edges, int combine, hipStream_t s) {
+                               uint32_t* bitmap32, const uint32_t* edges, int combine, hipStream_t s, int run_dwords) {
   if (n_pages <= 0 || edges == nullptr) return IPS_OK;
-  const int64_t tiles = (max_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int64_t tiles = (max_rows + (int64_t)run_dwords * 32 - 1) / ((int64_t)run_dwords * 32);
   hipLaunchKernelGGL(window_fixup_kernel, dim3((unsigned)((tiles + 1 + 255) / 256), (unsigned)n_pages), dim3(256), 0, s,
-                     d_pages, chunk_rows, bitmap32, edges, combine);
+                     d_pages, chunk_rows, bitmap32, edges, combine, run_dwords);
   IPS_HIP_TRY(hipGetLastError());
   return IPS_OK;
 }

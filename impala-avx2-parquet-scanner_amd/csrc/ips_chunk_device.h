@@ -139,26 +139,28 @@ __device__ __forceinline__ uint32_t window_operand(const BitmapWindow& w, int64_
   return d * 32 < w.n_rows ? w.base[d] : 0u;
 }
 
+// run >= 0: the run's index among the page's runs of (last_lane + 1) dwords = its edge slot (runs of 64: derived from d).
 __device__ __forceinline__ void window_emit(const BitmapWindow& w, WindowCarry& cy, int64_t d, uint32_t bm, int combine,
-                                            int last_lane = kWave - 1, const uint32_t* old = nullptr) {
+                                            int last_lane = kWave - 1, const uint32_t* old = nullptr, int64_t run = -1) {
   const int lane = (int)(threadIdx.x & (kWave - 1));
   const int64_t valid = w.n_rows - d * 32;
   const uint32_t vm = lane > last_lane ? 0u : valid >= 32 ? ~0u : valid <= 0 ? 0u : ((1u << valid) - 1u);
   bm &= vm;
   uint32_t val = bm, mask = vm;
-  if (w.shift != 0u && w.edges != nullptr && last_lane == kWave - 1) {  // wave-uniform
+  if (w.shift != 0u && w.edges != nullptr && (last_lane == kWave - 1 || run >= 0)) {  // wave-uniform
     // Edge mode (sub-tile runs of 64 dwords): the run's two end dwords -- the low part of lane 0, the
     // high part of lane 63 -- go to the sub-tile's edge slot with plain stores and window_fixup_kernel
     // merges neighbouring sub-tiles' parts afterwards: no atomics in this kernel, any sub-tile order.
     const uint32_t s = w.shift, r = 32u - s;
     const uint32_t up_bm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bm, 0x138, 0xF, 0xF, true);  // wave_shr:1
     const uint32_t up_vm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vm, 0x138, 0xF, 0xF, true);
-    uint32_t* slot = w.edges + 4 * ((d - lane) >> 6);
+    uint32_t* slot = w.edges + 4 * (run >= 0 ? run : ((d - lane) >> 6));
     if (lane == 0) {
       slot[0] = bm << s;
       return;
     }
-    if (lane == kWave - 1) slot[1] = bm >> r;
+    if (lane == last_lane) slot[1] = bm >> r;
+    if (lane > last_lane) return;  // (the dword behind the run belongs to the next run's lane 0)
     val = (bm << s) | (up_bm >> r);
     mask = (vm << s) | (up_vm >> r);
   } else if (w.shift != 0u) {  // wave-uniform

@@ -55,7 +55,7 @@ ips_status launch_plain_select_pages(int stride_bytes, const ChunkPage* d_pages,
                                      uint32_t* batch_counts, hipStream_t s);
 // edge mode's second launch over the same pages (ips_chunk.hip)
 ips_status launch_window_fixup(const ChunkPage* d_pages, int n_pages, int64_t max_rows, int64_t chunk_rows,
-                               uint32_t* bitmap32, const uint32_t* edges, int combine, hipStream_t s);
+                               uint32_t* bitmap32, const uint32_t* edges, int combine, hipStream_t s, int run_dwords = 64);
 // ips_chunk_select_nullable's first three launches (ips_rank.hip): the pages' selections as aligned bitmaps, the
 // three count tables per page, the pages' first selected / first selected NOT-NULL row and the totals
 ips_status launch_selnull_pages_prepare(const ChunkPage* d_pages, int n_pages, int64_t max_rows, const uint64_t* d_sel,

@@ -911,6 +911,70 @@ ips_status check_chunk_program(const ips_node* nodes, int n_nodes, const ips_chu
 
 }  // namespace
 
+namespace {
+// A plan that the one-pass chain can take over page lists: its operands, their page tables, and whether all
+// chunks are cut at the same rows
+struct ChunkChain {
+  ChainOpW ops[kChainWMaxOps];
+  const void* op_pages[kChainWMaxOps];
+  int op_n_pages[kChainWMaxOps];
+  const ips_chunk* c0;
+  bool co_paged;
+  int n_bounds;       // page starts of all operands
+  int64_t max_rows;   // of the largest page of any operand
+};
+bool chunk_chain(const Plan& pl, const ips_chunk* const* chunks, ChunkChain* cc) {
+  const int strategy = g_program_strategy.load(std::memory_order_relaxed);
+  if (!(pl.n_slots == 1 && pl.n_steps >= 2 && pl.n_steps <= kChainWMaxOps &&
+        (strategy == IPS_PROGRAM_AUTO || strategy == IPS_PROGRAM_ONE_PASS)))
+    return false;
+  memset(cc->ops, 0, sizeof(cc->ops));
+  cc->c0 = chunks[pl.steps[0].item.a->column];
+  cc->co_paged = true;
+  cc->n_bounds = 0;
+  cc->max_rows = 0;
+  for (int i = 0; i < pl.n_steps; ++i) {
+    const Step& p = pl.steps[i];
+    if (p.kind != 0) return false;
+    const ips_node* la = p.item.a;
+    const ips_node* lb = p.item.b;
+    const ips_chunk* c = chunks[la->column];
+    if (!(c->encoding == IPS_COL_FLE && c->max_def_level == 0 && c->runs.size() == 1 && !la->inset &&
+          (i == 0 ? p.combine == 0 : p.combine != 0)))
+      return false;
+    if (strategy == IPS_PROGRAM_AUTO && c->runs[0].bit_width == 32 && la->op != IPS_OP_IN) return false;
+    if (c->pages.size() != cc->c0->pages.size()) cc->co_paged = false;
+    for (size_t k = 0; cc->co_paged && k < c->pages.size(); ++k) cc->co_paged = c->pages[k].n_rows == cc->c0->pages[k].n_rows;
+    PredArgs folded;  // constants that do not fit the chunk's width make their comparison constant
+    run_pred_args(c->runs[0].bit_width, la->op, la->consts, la->n_consts, lb ? p.item.join : 0, lb ? lb->op : 0,
+                  lb ? lb->consts[0] : 0, p.combine, &folded);
+    ChainOpW& o = cc->ops[i];
+    o.w = c->runs[0].bit_width;
+    o.op = folded.op;
+    o.c1 = folded.consts[0];
+    o.combine = p.combine;
+    if (folded.op == IPS_OP_IN) {
+      if (folded.n_consts > 16) return false;
+      o.kind = kChainIn;
+      o.n_in = folded.n_consts;
+      for (int j = 0; j < folded.n_consts; ++j) o.in_consts[j] = folded.consts[j];
+    } else if (lb) {
+      o.kind = kChainPair;
+      o.join = folded.join;
+      o.op2 = folded.op2;
+      o.c2 = folded.const2;
+    } else {
+      o.kind = kChainSingle;
+    }
+    cc->op_pages[i] = c->d_pages;
+    cc->op_n_pages[i] = (int)c->pages.size();
+    cc->n_bounds += (int)c->pages.size();
+    cc->max_rows = c->runs[0].max_rows > cc->max_rows ? c->runs[0].max_rows : cc->max_rows;
+  }
+  return true;
+}
+}  // namespace
+
 extern "C" size_t ips_chunk_program_workspace_bytes(const ips_node* nodes, int n_nodes,
                                                     const ips_chunk* const* chunks, int n_chunks) {
   int64_t n_rows = 0;
@@ -920,6 +984,10 @@ extern "C" size_t ips_chunk_program_workspace_bytes(const ips_node* nodes, int n
   size_t bytes = pl.n_slots > 1 ? plan_slot_bytes(n_rows) * (size_t)(pl.n_slots - 1) : 0;
   for (int c = 0; c < n_chunks; ++c)
     if (chunks[c]->max_def_level > 0 && column_used(nodes, n_nodes, c)) bytes += align256z((size_t)chunks[c]->rank_entries * 4);
+  ChunkChain cc;  // a one-pass chain over chunks cut at different rows: the segment tables and edge slots
+  if (n_rows > 0 && g_program_strategy.load(std::memory_order_relaxed) == IPS_PROGRAM_ONE_PASS &&
+      chunk_chain(pl, chunks, &cc) && !cc.co_paged && cc.n_bounds <= kChainSegMaxBounds)
+    bytes += chain_segments_workspace_bytes(cc.n_bounds, n_rows);
   return bytes;
 }
 
@@ -938,9 +1006,18 @@ ips_status eval_program_chunks_signalled(const ips_node* nodes, int n_nodes, con
     return IPS_ERR_INVALID_ARG;
   }
   if (n_rows == 0) return IPS_OK;
+  // (the segment tables of a one-pass chain over differently cut chunks are the one optional part of the workspace:
+  // without it such a plan takes the per-operand launches)
+  ChunkChain cc;
+  const bool chain = chunk_chain(pl, chunks, &cc);
+  // (chunks cut at different rows: the segmented chain is what IPS_PROGRAM_ONE_PASS asks for; AUTO keeps the
+  // per-operand launches, which measure the same or better -- 417 us against 410 on the Q6 shape, ips_chain.hip)
+  const bool segmented = chain && !cc.co_paged && cc.n_bounds <= kChainSegMaxBounds &&
+                         g_program_strategy.load(std::memory_order_relaxed) == IPS_PROGRAM_ONE_PASS;
   const size_t need = ips_chunk_program_workspace_bytes(nodes, n_nodes, chunks, n_chunks);
-  IPS_REQUIRE(need == 0 || (d_workspace && aligned16(d_workspace)),
+  IPS_REQUIRE(need == 0 || segmented || (d_workspace && aligned16(d_workspace)),
               "ips_eval_program_chunks: pass a workspace of ips_chunk_program_workspace_bytes() bytes");
+  IPS_REQUIRE(!d_workspace || aligned16(d_workspace), "ips_eval_program_chunks: misaligned workspace");
   uint8_t* temp = reinterpret_cast<uint8_t*>(d_workspace);
   const size_t slot_bytes = plan_slot_bytes(n_rows);
   ChunkCtx ctx;
@@ -956,62 +1033,34 @@ ips_status eval_program_chunks_signalled(const ips_node* nodes, int n_nodes, con
     if (slot == pl.root) return d_bitmap;
     return reinterpret_cast<uint64_t*>(temp + slot_bytes * (size_t)(slot < pl.root ? slot : slot - 1));
   };
-  // A chain over REQUIRED FLE chunks whose pages hold the same rows in every chunk runs as ONE launch
-  // (ips_chain.hip: blockIdx.y = page); pages cut differently per column, OPTIONAL chunks, dictionary widths
-  // that grow inside a chunk and 32-bit comparisons (AUTO) take the per-operand launches below.
-  const int strategy = g_program_strategy.load(std::memory_order_relaxed);
-  if (pl.n_slots == 1 && pl.n_steps >= 2 && pl.n_steps <= kChainWMaxOps &&
-      (strategy == IPS_PROGRAM_AUTO || strategy == IPS_PROGRAM_ONE_PASS)) {
-    ChainPagedArgsW pa;
-    memset(&pa, 0, sizeof(pa));
-    const void* op_pages[kChainWMaxOps];
-    bool ok = true;
-    const ips_chunk* c0 = chunks[pl.steps[0].item.a->column];
-    for (int i = 0; i < pl.n_steps && ok; ++i) {
-      const Step& p = pl.steps[i];
-      const ips_node* la = p.item.a;
-      const ips_node* lb = p.item.b;
-      const ips_chunk* c = chunks[la->column];
-      ok = p.kind == 0 && c->encoding == IPS_COL_FLE && c->max_def_level == 0 && c->runs.size() == 1 && !la->inset &&
-           (i == 0 ? p.combine == 0 : p.combine != 0) && c->pages.size() == c0->pages.size();
-      if (ok && strategy == IPS_PROGRAM_AUTO && c->runs[0].bit_width == 32 && la->op != IPS_OP_IN) ok = false;
-      for (size_t k = 0; ok && k < c->pages.size(); ++k) ok = c->pages[k].n_rows == c0->pages[k].n_rows;
-      if (!ok) break;
-      PredArgs folded;  // constants that do not fit the chunk's width make their comparison constant
-      run_pred_args(c->runs[0].bit_width, la->op, la->consts, la->n_consts, lb ? p.item.join : 0, lb ? lb->op : 0,
-                    lb ? lb->consts[0] : 0, p.combine, &folded);
-      ChainOpW& o = pa.chain.ops[i];
-      o.w = c->runs[0].bit_width;
-      o.op = folded.op;
-      o.c1 = folded.consts[0];
-      o.combine = p.combine;
-      if (folded.op == IPS_OP_IN) {
-        ok = folded.n_consts <= 16;
-        o.kind = kChainIn;
-        o.n_in = folded.n_consts;
-        for (int j = 0; j < folded.n_consts && j < 16; ++j) o.in_consts[j] = folded.consts[j];
-      } else if (lb) {
-        o.kind = kChainPair;
-        o.join = folded.join;
-        o.op2 = folded.op2;
-        o.c2 = folded.const2;
-      } else {
-        o.kind = kChainSingle;
-      }
-      op_pages[i] = c->d_pages;
-    }
-    if (ok) {
+  // A chain over REQUIRED FLE chunks runs as ONE pass (ips_chain.hip): pages that hold the same rows in every
+  // chunk with blockIdx.y = page; pages cut differently per column with blockIdx.y = segment (the rows between
+  // two neighbouring page starts of any operand).  OPTIONAL chunks, dictionary widths that grow inside a chunk and
+  // 32-bit comparisons (AUTO) take the per-operand launches below.
+  if (chain) {
+    uint32_t* bm32 = reinterpret_cast<uint32_t*>(d_bitmap);
+    if (cc.co_paged) {
+      ChainPagedArgsW pa;
+      memset(&pa, 0, sizeof(pa));
+      memcpy(pa.chain.ops, cc.ops, sizeof(cc.ops));
       pa.chain.n_ops = pl.n_steps;
       pa.pg.chunk_rows = n_rows;
-      pa.pg.edges = done ? nullptr : c0->d_edges;  // (a signalling launch merges its shared dwords itself)
+      pa.pg.edges = done ? nullptr : cc.c0->d_edges;  // (a signalling launch merges its shared dwords itself)
       pa.pg.done = done;
       pa.pg.done_page0 = 0;
       pa.pg.done_epoch = done_epoch;
-      uint32_t* bm32 = reinterpret_cast<uint32_t*>(d_bitmap);
-      st = launch_chain_w_pages(pa, op_pages, (int)c0->pages.size(), c0->runs[0].max_rows, bm32, s);
+      st = launch_chain_w_pages(pa, cc.op_pages, (int)cc.c0->pages.size(), cc.c0->runs[0].max_rows, bm32, s);
       if (st == IPS_OK && pa.pg.edges)
-        st = launch_window_fixup(c0->d_pages, (int)c0->pages.size(), c0->runs[0].max_rows, n_rows, bm32, c0->d_edges, 0, s);
+        st = launch_window_fixup(cc.c0->d_pages, (int)cc.c0->pages.size(), cc.c0->runs[0].max_rows, n_rows, bm32, cc.c0->d_edges, 0, s);
       if (st == IPS_OK && done && signalled) *signalled = true;
+      if (st != IPS_ERR_UNSUPPORTED) return st;
+      st = IPS_OK;
+    } else if (!done && segmented && temp != nullptr) {
+      ChainSegmentedArgsW sa;
+      memset(&sa, 0, sizeof(sa));
+      memcpy(sa.chain.ops, cc.ops, sizeof(cc.ops));
+      sa.chain.n_ops = pl.n_steps;
+      st = launch_chain_w_segments(sa, cc.op_pages, cc.op_n_pages, cc.max_rows, n_rows, bm32, temp, s);
       if (st != IPS_ERR_UNSUPPORTED) return st;
       st = IPS_OK;
     }

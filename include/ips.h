@@ -435,7 +435,9 @@ typedef struct {
  * OR-ing into a bitmap -- those kernels run at 70-80 % of the HBM roofline.  ONE_PASS: a left-deep
  * conjunct / disjunct chain of two to six operands on REQUIRED FLE columns (comparisons, pairs, IN
  * lists of up to 16 constants; at most 16 KiB of planes per 2048 rows) as ONE kernel that reads every
- * column once and writes the bitmap once; other trees fall back to PER_OPERAND.  AUTO (the default):
+ * column once and writes the bitmap once -- over page lists too: chunks cut at the same rows page by page,
+ * chunks cut at different rows segment by segment (ips_eval_program_chunks; the latter only under ONE_PASS:
+ * it ties the per-operand launches); other trees fall back to PER_OPERAND.  AUTO (the default):
  * ONE_PASS for such chains unless one of them compares a 32-bit column (its stand-alone kernel skips
  * the low planes of decided sub-tiles), PER_OPERAND otherwise.  ONE_LAUNCH: the whole tree as one
  * stack-machine kernel (REQUIRED columns only; 2-3x slower, for callers that must have a single

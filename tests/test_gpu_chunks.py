@@ -353,13 +353,17 @@ def test_bitmap_batch_counts(capi):
         assert np.array_equal(got, exp), n
 
 
+@pytest.mark.parametrize("common", [True, False])
 @pytest.mark.parametrize("seed", range(5))
-def test_chunk_program_one_pass_over_common_pages(capi, O, seed, request):
+def test_chunk_program_one_pass_over_common_pages(capi, O, seed, common, request):
     """ips_eval_program_chunks on a conjunct / disjunct chain over REQUIRED FLE chunks whose pages hold the SAME
     rows in every chunk (what a writer that flushes all columns of a row group together produces): ONE launch,
     blockIdx.y = page, every operand in its own block geometry (ips_chain.hip).  Pages of every awkward size --
     page starts inside bitmap dwords (edge slots + fix-up), pages smaller than a dword, empty pages -- against
-    numpy on the raw values and against the per-operand plan; constants that do not fit a chunk's width."""
+    numpy on the raw values and against the per-operand plan; constants that do not fit a chunk's width.
+    common = False: every column is cut at its OWN rows (what column writers produce): the chain walks the segments
+    between neighbouring page starts of any operand (blockIdx.y = segment), each operand from wherever the segment
+    starts inside its page."""
     request.addfinalizer(lambda: capi.set_program_strategy(capi.PROGRAM_AUTO))
     rng = np.random.default_rng(900 + seed)
     n = int(rng.choice([1, 37, 4096, 70001, 300007]))
@@ -373,7 +377,8 @@ def test_chunk_program_one_pass_over_common_pages(capi, O, seed, request):
         w = int(rng.integers(1, 25))
         span = (1 << w) - 1 if rng.random() < 0.6 else min((1 << w) - 1, 15)
         v = rng.integers(0, span + 1, n, dtype=np.uint64).astype(np.uint32)
-        ch, _ = fle_chunk(capi, O, v, page_rows, lambda k, w=w: w)
+        own = page_rows if common else cuts(rng, n, [RAGGED, [2048, 4096, 100], [1, 5, 31, 33, 700], [70001, 10000, 0], [32, 64, 2048 + 32, 1984]][(seed + i) % 5])
+        ch, _ = fle_chunk(capi, O, v, own, lambda k, w=w: w)
         chunks.append(ch)
         kind = rng.integers(0, 3)
         # now and then a constant beyond the column's width (unsigned SQL meaning: LT / LE always, else never)
@@ -409,12 +414,13 @@ def test_chunk_program_one_pass_over_common_pages(capi, O, seed, request):
         else:
             nodes.append(OR())
             exp = exp | sel
-    for strat in (capi.PROGRAM_AUTO, capi.PROGRAM_PER_OPERAND):
+    # (ONE_PASS: chunks cut at different rows take the segmented chain; AUTO keeps the per-operand launches for them)
+    for strat in (capi.PROGRAM_AUTO, capi.PROGRAM_ONE_PASS, capi.PROGRAM_PER_OPERAND):
         capi.set_program_strategy(strat)
         bm = torch.full(((n + 63) // 64 + 2,), -1, dtype=torch.int64, device="cuda")  # (no zero-initialised bitmap needed)
         capi.eval_program_chunks(nodes, chunks, bitmap=bm)
         got_words = words(bm)[:(n + 63) // 64]
-        assert np.array_equal(bits_of(got_words, n), exp), (seed, strat, n, page_rows[:8])
+        assert np.array_equal(bits_of(got_words, n), exp), (seed, common, strat, n, page_rows[:8])
         if n % 64:
             assert int(got_words[-1]) >> (n % 64) == 0, "bits behind the last row are zero"
     for ch in chunks:

@@ -35,14 +35,17 @@ def bits_of(t, n):
 bad = 0
 for it in range(ITERS):
     n = int(rng.choice([1, 70, 2048, 2049, 3000, 2048 * 7, int(rng.integers(1, 400000))]))
-    paged = rng.random() < 0.5
-    page_rows = []
-    if paged:
-        left = n
+    paged = rng.random() < 0.7
+    own_cuts = paged and rng.random() < 0.6   # every column cut at its own rows: the segmented chain
+
+    def make_cuts():
+        out, left = [], n
         while left > 0:
             s = min(int(rng.choice(SIZES)), left)
-            page_rows.append(s)
+            out.append(s)
             left -= s
+        return out
+    page_rows = make_cuts() if paged else []
     n_ops = int(rng.integers(2, 7))
     cols, keep, nodes, exp = [], [], [], None
     for i in range(n_ops):
@@ -51,7 +54,7 @@ for it in range(ITERS):
         v = rng.integers(0, span + 1, n, dtype=np.uint64).astype(np.uint32)
         if paged:
             pages, pos = [], 0
-            for m in page_rows:
+            for m in (make_cuts() if own_cuts else page_rows):
                 enc = O.fle_encode(v[pos:pos + m], w) if m else np.zeros(2, np.uint64)
                 pages.append((dev_words(enc), m, w))
                 pos += m
@@ -91,7 +94,7 @@ for it in range(ITERS):
     capi.set_program_strategy(capi.PROGRAM_AUTO)
     if not all(np.array_equal(r, exp) for r in res):
         bad += 1
-        print("chain mismatch: iter", it, "n", n, "paged", paged, "ops", n_ops, [np.array_equal(r, exp) for r in res])
+        print("chain mismatch: iter", it, "n", n, "paged", paged, "own cuts", own_cuts, "ops", n_ops, [np.array_equal(r, exp) for r in res])
     if paged:
         for c in cols:
             c.close()
