@@ -87,7 +87,7 @@ struct ChainSegArgs {
   int64_t chunk_rows;
   uint32_t* edges;
   int32_t n_bounds;                         // segments (page starts of all operands, ties kept: some are empty)
-  int32_t reserved;
+  int32_t image_dwords;                     // per wave: ONE plane image, the widest operand's
 };
 struct ChainSegmentedArgsW {
   ChainArgsW chain;

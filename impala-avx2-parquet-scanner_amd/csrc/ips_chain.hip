@@ -292,13 +292,13 @@ __global__ __launch_bounds__(kThreads, chain_min_waves(LTOT, MAXW)) void fle_cha
 // asynchronous and allocation-free: ranks by binary search in an LDS copy of the starts; it also deals the
 // chain's workgroups (four stripes each) to the segments, so that no workgroup is without work.
 // Measured on the Q6 shape (pages of 2^20 / 2^20 - 37 / 700 001 rows: 2002 segments of 37 .. 700 001 rows):
-// the chain kernel 352 us + the merge 25-49 us + the fix-up 9 us = 400-426 us against 417 us for the three
-// per-operand launches with their fix-ups -- a tie, which is why only IPS_PROGRAM_ONE_PASS selects it.  The wave
-// of a stripe sits behind three dependent rounds of loads (its segment's number, the segment's tables, the data;
-// the contiguous chain: one, the chain over common pages: two) and the 6.4 KiB of plane images per wave
-// bound the resident waves at six per SIMD, so every extra round costs ~0.85 us x 303 000 stripes / 6144 waves.
-// With blockIdx.y = segment instead of the workgroup map 41 % of the wave slots stayed idle (segments of 1 to
-// 353 stripes): the same 352 us.
+// the chain kernel 345 us + the merge 50 us + the fix-up 10 us = 400 us against 417-429 us for the three
+// per-operand launches with their fix-ups -- 5 % apart, which is why only IPS_PROGRAM_ONE_PASS selects it.  The
+// wave of a stripe sits behind three dependent rounds of loads (its segment's number, the segment's tables, the
+// data; the contiguous chain: one, the chain over common pages: two).  Tried: blockIdx.y = segment with a
+// looping wave (41 % of the wave slots idle, segments of 1 to 353 stripes: 352 us), a grid sized for the longest
+// segment (500 us: the workgroups without work), all operands' images resident (6 waves per SIMD: 352 us; now one
+// image per wave, 8 waves: 345 us).
 // ---------------------------------------------------------------------------------------------
 typedef const ChainSegmentedArgsW __attribute__((address_space(4))) * ChainSegArgsK;
 
@@ -403,15 +403,26 @@ __global__ __launch_bounds__(1024) void chain_segments_kernel(ChainSegArgs sg, i
   }
   uint32_t at = scan[threadIdx.x] - (c0 + c1 + c2 + c3);  // workgroups in front of segment r0
   const uint32_t cnt[4] = {c0, c1, c2, c3};
+  uint32_t* first_wg = scan + 1024;   // [segment]: its first workgroup and its count, for the fill below
+  uint32_t* n_of_seg = scan + 1024 + kChainSegMaxBounds;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (r0 + k < n_bounds) {
       seg_wg0[r0 + k] = at;
-      for (uint32_t g = 0; g < cnt[k]; ++g) wg_seg[at + g] = (uint32_t)(r0 + k);
+      first_wg[r0 + k] = at;
+      n_of_seg[r0 + k] = cnt[k];
       at += cnt[k];
     }
   }
   if (threadIdx.x == 1023) *n_wgs = scan[1023];
+  __syncthreads();
+  // a wave per segment, a lane per workgroup: coalesced stores (a thread per segment wrote up to 89 entries
+  // one after the other: 20 us of the kernel)
+  const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
+  for (int r = wv; r < n_bounds; r += 16) {
+    const uint32_t w0 = first_wg[r], cn = n_of_seg[r];
+    for (uint32_t g = (uint32_t)lane; g < cn; g += 64u) wg_seg[w0 + g] = (uint32_t)r;
+  }
 }
 
 template <int LTOT, int MAXW>
@@ -429,7 +440,7 @@ __global__ __launch_bounds__(kThreads, chain_min_waves(LTOT, MAXW)) void fle_cha
   // one stripe per wave, four consecutive ones per workgroup
   const int64_t t = (int64_t)(blockIdx.x - sa->sg.seg_wg0[si]) * kWavesPerBlock + wave;
   if (t * kChainSegRows >= seg.n_rows) return;
-  uint32_t* lds32 = lds_all + wave * a->image_dwords;
+  uint32_t* lds32 = lds_all + wave * sa->sg.image_dwords;
   const BitmapWindow win = bitmap_window(bitmap32, seg, sa->sg.chunk_rows, nullptr, sa->sg.edges);
   const int n_ops = a->n_ops;
   const uint32_t lane_byte = (uint32_t)lane * 16u;
@@ -455,27 +466,32 @@ __global__ __launch_bounds__(kThreads, chain_min_waves(LTOT, MAXW)) void fle_cha
                                                                  tile_bytes ? (int)left : 0, kBufferRsrcDword3),
                                in_tile < tile_bytes ? in_tile : 0xFFFFFFF0u);
   }
-#pragma unroll
-  for (int i = 0; i < LTOT; ++i) {
-    const uint32_t first = a->slots[i].first_byte, tile_bytes = a->slots[i].tile_bytes;
-    const uint32_t in_tile = first + lane_byte;
-    if (in_tile < tile_bytes) {
-      const uint32_t w = tile_bytes >> 8;
-      const uint32_t wi = in_tile >> 3;
-      const uint32_t blk = __umulhi(wi, a->slots[i].inv_w);
-      uint32_t* dst = lds32 + a->slots[i].img_dw + 2 * (blk * (w | 1u) + (wi - blk * w));
-      const u32x2 lo = {r[i].x, r[i].y}, hi = {r[i].z, r[i].w};
-      *reinterpret_cast<u32x2*>(dst) = lo;
-      *reinterpret_cast<u32x2*>(dst + 2) = hi;
-    }
-  }
-  wave_lds_fence();
+  // ONE plane image per wave, the widest operand's: the operands are staged from the slot registers one after the
+  // other (the LDS a wave holds bounds the resident waves, and a stripe's wave lives through three rounds of loads)
   uint32_t acc = 0u;
 #pragma unroll 1
   for (int i = 0; i < n_ops; ++i) {
     const ChainStep o = chain_step(a, i);
+#pragma unroll
+    for (int k = 0; k < LTOT; ++k) {
+      if (sa->sg.slot_op[k] == i) {  // wave-uniform
+        const uint32_t first = a->slots[k].first_byte, tile_bytes = a->slots[k].tile_bytes;
+        const uint32_t in_tile = first + lane_byte;
+        if (in_tile < tile_bytes) {
+          const uint32_t w = tile_bytes >> 8;
+          const uint32_t wi = in_tile >> 3;
+          const uint32_t blk = __umulhi(wi, a->slots[k].inv_w);
+          uint32_t* dst = lds32 + 2 * (blk * (w | 1u) + (wi - blk * w));
+          const u32x2 lo = {r[k].x, r[k].y}, hi = {r[k].z, r[k].w};
+          *reinterpret_cast<u32x2*>(dst) = lo;
+          *reinterpret_cast<u32x2*>(dst + 2) = hi;
+        }
+      }
+    }
+    wave_lds_fence();
     uint32_t sel = 0u;
-    width_switch<MAXW>(o.w, [&](auto W) { sel = chain_eval<decltype(W)::value>(lds32 + o.img_dw, lane, o); });
+    width_switch<MAXW>(o.w, [&](auto W) { sel = chain_eval<decltype(W)::value>(lds32, lane, o); });
+    wave_lds_fence();  // the image is rewritten by the next operand
     // rows 32 l .. 32 l + 31 of the sub-tile -> rows of the stripe: the segment starts 'bit' rows into the block
     uint32_t bit = op_bit[0];
 #pragma unroll
@@ -588,7 +604,7 @@ template <int LTOT, int MAXW>
 static ips_status launch_chain_w_segments_class(const ChainSegmentedArgsW& sa, int64_t chunk_rows, uint32_t* bitmap32,
                                                 hipStream_t s) {
   auto kern = fle_chain_w_segments_kernel<LTOT, MAXW>;
-  const size_t lds = (size_t)kWavesPerBlock * sa.chain.image_dwords * 4;
+  const size_t lds = (size_t)kWavesPerBlock * sa.sg.image_dwords * 4;
   hipLaunchKernelGGL(kern, dim3((unsigned)chain_seg_max_wgs(sa.sg.n_bounds, chunk_rows)), dim3(kThreads), lds, s, sa, bitmap32);
   IPS_HIP_TRY(hipGetLastError());
   return IPS_OK;
@@ -669,6 +685,7 @@ ips_status launch_chain_w_segments(ChainSegmentedArgsW& sa, const void* const* o
     sa.sg.op_n_pages[i] = i < sa.chain.n_ops ? op_n_pages[i] : 0;
     sa.sg.op_w[i] = i < sa.chain.n_ops ? sa.chain.ops[i].w : 0;
   }
+  sa.sg.image_dwords = plane_tile_bytes(maxw) / 4;  // one image per wave, the widest operand's
   for (int i = 0; i < kChainWMaxSlots; ++i) {
     sa.sg.slot_op[i] = i < sa.chain.n_slots ? (int)sa.chain.slots[i].rsrc[0] : 0;
     sa.sg.slot_pages[i] = op_pages[sa.sg.slot_op[i]];

@@ -78,6 +78,12 @@ def main():
         t, tmin = timeit(lambda: capi.eval_program_chunks(nodes, chunks, bitmap=bm2))
         report(f"Q6 conjunction over page lists, {label}", t, tmin, t_c, torch.equal(bm2, ref),
                pages_per_column=[len(page_cuts(n, s)) for s in sizes])
+        if rows is None:  # the segmented one-pass chain (IPS_PROGRAM_ONE_PASS; AUTO keeps the per-operand launches)
+            capi.set_program_strategy(capi.PROGRAM_ONE_PASS)
+            t, tmin = timeit(lambda: capi.eval_program_chunks(nodes, chunks, bitmap=bm2))
+            capi.set_program_strategy(capi.PROGRAM_AUTO)
+            report(f"Q6 conjunction over page lists, {label}: segmented one-pass chain (ONE_PASS)", t, tmin, t_c,
+                   torch.equal(bm2, ref))
         for ch in chunks:
             ch.close()
         del chunks
