@@ -548,12 +548,18 @@ def test_entry_points_capture_into_a_graph(capi, O):
         capi._ck(capi.lib().ips_eval_program(arr_n, len(tree), arr_c, len(cols), C.c_int64(n),
                                              C.c_void_p(bm_tree.data_ptr()), None, capi._stream()))
 
+    # the same chain over the two columns as page lists (one page each, the very buffers above): the one-pass
+    # chain with blockIdx.y = page
+    chunks = [capi.Chunk([(ea, n, 12)]), capi.Chunk([(eb, n, 6)])]
+    bm_pages = torch.zeros_like(bm_pred)
+
     def work():
         capi.fle_pred(ea, n, 12, O.OP_LT, 1000, bitmap=bm_pred)
         capi.fle_scan(ea, n, 12, O.OP_LT, 1000, outputs=outs)
         capi.fle_scan_pages(plist, 12, O.OP_GE, 2000)
         capi.eval_program(chain, cols, n, bitmap=bm_chain)
         capi.eval_program(tree, cols, n, bitmap=bm_tree, workspace=ws_tree)
+        capi.eval_program_chunks(chain, chunks, bitmap=bm_pages)
 
     work()                                   # warm-up outside the capture (module loading etc.)
     torch.cuda.synchronize()
@@ -567,7 +573,7 @@ def test_entry_points_capture_into_a_graph(capi, O):
     # new data in the same buffers, then replay
     a2 = rng.integers(0, 1 << 12, n).astype(np.uint32)
     ea.copy_(dev_words(O.fle_encode(a2, 12)))
-    for t in (bm_pred, bm_chain, bm_tree, outs[0], pages[0][2][0]):
+    for t in (bm_pred, bm_chain, bm_tree, bm_pages, outs[0], pages[0][2][0]):
         t.zero_()
     g.replay()
     torch.cuda.synchronize()
@@ -576,6 +582,7 @@ def test_entry_points_capture_into_a_graph(capi, O):
     assert np.array_equal(bits_of(words(outs[0][:W]), n), a2 < 1000)
     assert np.array_equal(bits_of(words(pages[0][2][0][:W]), n), a2 >= 2000)
     assert np.array_equal(bits_of(words(bm_chain[:W]), n), (a2 >= 100) & (a2 < 3000) & (b < 40))
+    assert np.array_equal(bits_of(words(bm_pages[:W]), n), (a2 >= 100) & (a2 < 3000) & (b < 40))
     assert np.array_equal(bits_of(words(bm_tree[:W]), n),
                           ((a2 < 500) & (b >= 10)) | ((a2 >= 3500) & (b < 5)))
 
