@@ -71,7 +71,6 @@ struct ChainSegSlot {
   int64_t blocks;         // blocks the page holds from there on
 };
 struct ChainSegArgs {
-  const void* slot_pages[kChainWMaxSlots];  // per load slot: its operand's ChunkPage table (whole chunk)
   const void* op_pages[kChainWMaxOps];      // per operand
   int32_t op_n_pages[kChainWMaxOps];
   int32_t slot_op[kChainWMaxSlots];         // the slot's operand

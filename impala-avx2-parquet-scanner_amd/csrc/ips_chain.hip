@@ -688,7 +688,6 @@ ips_status launch_chain_w_segments(ChainSegmentedArgsW& sa, const void* const* o
   sa.sg.image_dwords = plane_tile_bytes(maxw) / 4;  // one image per wave, the widest operand's
   for (int i = 0; i < kChainWMaxSlots; ++i) {
     sa.sg.slot_op[i] = i < sa.chain.n_slots ? (int)sa.chain.slots[i].rsrc[0] : 0;
-    sa.sg.slot_pages[i] = op_pages[sa.sg.slot_op[i]];
   }
   sa.sg.seg_pages = w.seg_pages;
   sa.sg.seg_slots = w.seg_slots;

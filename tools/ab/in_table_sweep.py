@@ -20,7 +20,7 @@ for bw in (8, 12, 16):
     enc = capi.fle_encode(vals, bw)
     outs = capi.alloc_scan_outputs(n, dev)
     D = 1 << bw
-    for K in (8, 16, 24, 32, 48, 64, 128):
+    for K in (8, 12, 16, 20, 24, 32, 48, 64, 128):
         if K > D // 4:
             continue
         codes = [int(x) for x in np.linspace(1, D - 2, K).astype(int)]
