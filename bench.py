@@ -634,7 +634,11 @@ def main():
     # ---- configs[4] sharded: the Q6 conjunction over block-cyclic stripes + chunked gather ------
     q6_sharded = None
     if gather and not args.no_extra:
-        q6_sharded = leg_q6_sharded(ips, capi, dev, dist, comm, comm_stream, world, rank)
+        try:  # a secondary leg: its failure must not take the headline line with it
+            q6_sharded = leg_q6_sharded(ips, capi, dev, dist, comm, comm_stream, world, rank)
+        except Exception as ex:
+            q6_sharded = {"config": "configs[4] TPC-H-Q6 shape sharded", "error": repr(ex), "check": False}
+            print(f"bench.py: Q6 sharded leg failed on rank {rank}: {ex!r}", file=sys.stderr)
 
     extra = {}
     if rank == 0 and not gather and not args.no_extra:
