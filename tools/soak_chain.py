@@ -34,7 +34,7 @@ def bits_of(t, n):
 
 bad = 0
 for it in range(ITERS):
-    n = int(rng.choice([1, 70, 2048, 2049, 3000, 2048 * 7, int(rng.integers(1, 400000))]))
+    n = int(rng.choice([1, 70, 2048, 2049, 3000, 2048 * 7, int(rng.integers(1, int(os.environ.get("IPS_SOAK_MAX_ROWS", "400000"))))]))
     paged = rng.random() < 0.7
     own_cuts = paged and rng.random() < 0.6   # every column cut at its own rows: the segmented chain
 
