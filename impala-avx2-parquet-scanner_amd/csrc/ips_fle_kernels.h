@@ -633,6 +633,96 @@ __device__ __forceinline__ void fle_pred_body(const uint64_t* __restrict__ enc, 
   __shared__ uint32_t in_table[kInTable ? InTable<W>::kDwords : 1];
   if constexpr (kInTable) in_table_build<W>(in_table, args);
 
+  // the rows of the sub-tile in the wave's plane image that satisfy the predicate (MSB first per lane)
+  auto evaluate = [&]() -> uint32_t {
+    if (KIND == kPredSingle) {
+      uint32_t p[W];
+      planes_from_lds<W>(lds32, lane, p);
+      return pred_from_regs<W>(p, args);
+    } else if (KIND == kPredPair) {
+      uint32_t r1, r2;
+      pred_pair_from_lds(lds32, W, lane, args.op, args.consts[0], args.op2, args.const2, &r1, &r2);
+      return args.join == 1 ? (r1 & r2) : (r1 | r2);
+    } else if (kInTable) {
+      uint32_t p[W];
+      planes_from_lds<W>(lds32, lane, p);
+      uint32_t v[32];
+      planes_to_values<W>(p, v);
+      return bitrev32(in_table_lookup(in_table, v));
+    } else if (W <= 16) {
+      uint32_t p[W];
+      planes_from_lds<W>(lds32, lane, p);
+      return pred_in_from_regs<W>(p, args.consts, args.n_consts);
+    } else {
+      return args.in_list ? pred_in_from_lds(lds32, W, lane, args.in_list, args.in_list_n)
+                          : pred_in_from_lds(lds32, W, lane, args.consts, args.n_consts);
+    }
+  };
+
+  // A page that starts inside a bitmap dword (and has no edge slots): STRIPES of 62 whole dwords of the chunk's
+  // bitmap = 1984 rows.  Stripe t covers page rows [1984 t - shift, 1984 (t + 1) - shift): whatever the shift,
+  // they lie inside the 32 blocks from block max(31 t - 1, 0) on, so the wave still evaluates one ordinary
+  // sub-tile (consecutive stripes re-read one block) and moves its result dwords into place with two DPP moves
+  // and a funnel shift.  Every dword but the page's first and last belongs to this wave alone: plain stores /
+  // read-modify-writes, no edge slots, no fix-up launch; the two end dwords are shared with the neighbouring
+  // pages and merged with masked atomics (window_put).  Against the edge-slot version (kept for the fused
+  // scans, whose batches are sub-tiles, and the early-pruning w = 32 predicate): Q6 over pages cut differently
+  // per column, three launches, 417-429 -> 388 us (the w = 12 BETWEEN launch 171 -> 155 us, three fix-up
+  // launches of 5-14 us gone).
+  if constexpr (PAGED) {
+    if (win->shift != 0u && win->edges == nullptr) {  // wave-uniform
+      constexpr int kRun = 62;
+      const uint32_t s = win->shift, rs = 32u - s;
+      const int64_t n_blocks = (n_rows + 63) / 64;
+      const int64_t stripes = (n_rows + s + kRun * 32 - 1) / (kRun * 32);
+      const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+      int64_t t = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+      auto load_stripe = [&](int64_t st, u32x4 (&rr)[L]) {
+        const int64_t b0 = st == 0 ? 0 : 31 * st - 1;
+        int64_t left = (n_blocks - b0) * W;  // words of the page from that block on
+        left = left < 0 ? 0 : (left > kBlocksPerTile * W ? kBlocksPerTile * W : left);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint64_t*>(left > 0 ? enc + b0 * W : enc), 0, (int)(left * 8), kBufferRsrcDword3);
+#pragma unroll
+        for (int i = 0; i < L; ++i) rr[i] = buffer_load16<true>(rsrc, (uint32_t)(i * kWave + lane) * 16u);
+      };
+      u32x4 rr[L];
+      if (t < stripes) load_stripe(t, rr);
+      while (t < stripes) {
+        tile_to_lds<L>(lds32, W, lane, rr);
+        const int64_t next = t + n_waves;
+        if (next < stripes) load_stripe(next, rr);
+        wave_lds_fence();
+        const uint32_t rows = bitrev32(evaluate());  // bit j <-> row 32 lane + j of the sub-tile
+        uint32_t out;
+        if (t == 0) {  // the page's first rows sit 'shift' bits into the first dword
+          const uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rows, 0x138, 0xF, 0xF, true);  // wave_shr:1
+          out = __builtin_amdgcn_alignbit(rows, below, rs);
+        } else {       // the stripe starts 64 - shift rows into block 31 t - 1
+          const uint32_t a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rows, 0x130, 0xF, 0xF, true);  // wave_shl:1
+          const uint32_t a2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a1, 0x130, 0xF, 0xF, true);
+          out = __builtin_amdgcn_alignbit(a2, a1, rs);
+        }
+        if (lane < kRun) {
+          const int64_t d = t * kRun + lane;            // dword of the window
+          const int64_t first = d * 32 - (int64_t)s;    // page row of its bit 0
+          uint32_t mask = ~0u;
+          if (first < 0) mask &= ~0u << (uint32_t)(-first);
+          const int64_t valid = n_rows - first;
+          if (valid < 32) mask &= valid <= 0 ? 0u : ((1u << valid) - 1u);
+          const uint32_t val = out & mask;  // (rows behind the page's last one evaluate to anything)
+          const bool tail = win->own_tail && d == win->tail_dword && mask != 0u;  // zeros behind the chunk's last row
+          if (tail) mask |= win->tail_mask;
+          window_put(win->base + d, val, mask, args.combine, 0u);
+          if (tail && win->tail_extra && args.combine != 2) window_store(win->base + d + 1, 0u, 0u);
+        }
+        wave_lds_fence();
+        t = next;
+      }
+      return;
+    }
+  }
+
   // The dword an AND-into / OR-into launch combines with travels with the register prefetch of its
   // sub-tile.  (Loaded where it is used -- after the predicate -- it put a whole memory round trip,
   // and a vmcnt(0) that also waited out the prefetched planes, at the end of every sub-tile.)
@@ -656,29 +746,7 @@ __device__ __forceinline__ void fle_pred_body(const uint64_t* __restrict__ enc, 
       tile_load<L>(enc, next, W, total_words, lane, r);
     }
     wave_lds_fence();
-    uint32_t sel;
-    if (KIND == kPredSingle) {
-      uint32_t p[W];
-      planes_from_lds<W>(lds32, lane, p);
-      sel = pred_from_regs<W>(p, args);
-    } else if (KIND == kPredPair) {
-      uint32_t r1, r2;
-      pred_pair_from_lds(lds32, W, lane, args.op, args.consts[0], args.op2, args.const2, &r1, &r2);
-      sel = args.join == 1 ? (r1 & r2) : (r1 | r2);
-    } else if (kInTable) {
-      uint32_t p[W];
-      planes_from_lds<W>(lds32, lane, p);
-      uint32_t v[32];
-      planes_to_values<W>(p, v);
-      sel = bitrev32(in_table_lookup(in_table, v));
-    } else if (W <= 16) {
-      uint32_t p[W];
-      planes_from_lds<W>(lds32, lane, p);
-      sel = pred_in_from_regs<W>(p, args.consts, args.n_consts);
-    } else {
-      sel = args.in_list ? pred_in_from_lds(lds32, W, lane, args.in_list, args.in_list_n)
-                           : pred_in_from_lds(lds32, W, lane, args.consts, args.n_consts);
-    }
+    const uint32_t sel = evaluate();
     uint32_t bm = finish_bitmap_dword(sel, tile, lane, n_rows);
     const int64_t d = tile * 64 + lane;
     if constexpr (PAGED) {

@@ -861,7 +861,10 @@ ips_status emit_item_chunk(const ChainItem& it, int combine, const ips_chunk* co
         args.aux_counts = ctx.rank[col];
         st = launch_fle_leaf_pages(run.bit_width, c->d_pages + run.first, run.count, run.max_rows, n_rows, args, bm32, s);
       } else {
-        args.edges = done ? nullptr : c->d_edges;  // (a signalling launch merges its shared dwords itself)
+        // pages that start inside a bitmap dword: fle_pred_body walks them in stripes of 62 whole dwords (no shared
+        // dwords but the page's two ends); only the early-pruning w = 32 kernel still uses the edge slots + fix-up
+        const bool early32 = run.bit_width == 32 && args.op != IPS_OP_IN;
+        args.edges = (done || !early32) ? nullptr : c->d_edges;  // (a signalling launch merges its shared dwords itself)
         st = launch_fle_pred_pages(run.bit_width, c->d_pages + run.first, run.count, run.max_rows, n_rows, args, bm32, s);
         if (st == IPS_OK && args.edges)
           st = launch_window_fixup(c->d_pages + run.first, run.count, run.max_rows, n_rows, bm32, c->d_edges, combine, s);

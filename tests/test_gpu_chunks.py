@@ -422,7 +422,7 @@ def test_chunk_program_one_pass_over_common_pages(capi, O, seed, common, request
         got_words = words(bm)[:(n + 63) // 64]
         assert np.array_equal(bits_of(got_words, n), exp), (seed, common, strat, n, page_rows[:8])
         if n % 64:
-            assert int(got_words[-1]) >> (n % 64) == 0, "bits behind the last row are zero"
+            assert int(got_words[-1]) >> (n % 64) == 0, ("bits behind the last row are zero", seed, common, strat, page_rows[-4:])
     for ch in chunks:
         ch.close()
 
