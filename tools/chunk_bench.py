@@ -41,13 +41,38 @@ def page_cuts(n, rows):
     return out
 
 
+SLAB = os.environ.get("IPS_PAGES_SLAB") == "1"
+
+
 def make_chunk(codes, w, cuts):
-    """separate device buffers, one per page (each encoded on its own: block geometry restarts)"""
+    """separate device buffers, one per page (each encoded on its own: block geometry restarts).
+    IPS_PAGES_SLAB=1: the page buffers are carved out of ONE allocation per column (256-byte aligned), as a scanner
+    that reads a column chunk into one slab holds them -- many small allocations of the caching allocator cost the
+    narrow kernels TLB reach."""
     pages, pos = [], 0
+    encs = []
     for m in cuts:
-        pages.append((capi.fle_encode(codes[pos:pos + m].clone(), w), m, w))
+        encs.append(capi.fle_encode(codes[pos:pos + m].clone(), w))
         pos += m
+    if SLAB:
+        offs, total = [], 0
+        for e in encs:
+            offs.append(total)
+            total += (e.numel() * 8 + 255) // 256 * 256 // 8
+        slab = torch.empty(total + 32, dtype=torch.int64, device=dev)
+        views = []
+        for e, o in zip(encs, offs):
+            v = slab[o:o + e.numel()]
+            v.copy_(e)
+            views.append(v)
+        encs = views
+        KEEP.append(slab)
+    for e, m in zip(encs, cuts):
+        pages.append((e, m, w))
     return capi.Chunk(pages)
+
+
+KEEP = []
 
 
 out = []
