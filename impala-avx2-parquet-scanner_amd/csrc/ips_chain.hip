@@ -292,8 +292,8 @@ __global__ __launch_bounds__(kThreads, chain_min_waves(LTOT, MAXW)) void fle_cha
 // asynchronous and allocation-free: ranks by binary search in an LDS copy of the starts; it also deals the
 // chain's workgroups (four stripes each) to the segments, so that no workgroup is without work.
 // Measured on the Q6 shape (pages of 2^20 / 2^20 - 37 / 700 001 rows: 2002 segments of 37 .. 700 001 rows):
-// the chain kernel 345 us + the merge 50 us + the fix-up 10 us = 397-405 us against 388-397 us for the three
-// per-operand launches (417-429 us before their 62-dword stripes) -- a tie, which is why only
+// the chain kernel 345 us + the merge 50 us + the fix-up 10 us = 397-405 us against 367 us for the three
+// per-operand launches (417-429 us before their 62-dword stripes) -- which is why only
 // IPS_PROGRAM_ONE_PASS selects it.  The
 // wave of a stripe sits behind three dependent rounds of loads (its segment's number, the segment's tables, the
 // data; the contiguous chain: one, the chain over common pages: two).  Tried: blockIdx.y = segment with a
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(kThreads, chain_min_waves(LTOT, MAXW)) void fle_cha
     acc = o.combine == 0 ? sel : o.combine == 1 ? (acc & sel) : (acc | sel);
   }
   WindowCarry carry;
-  window_emit(win, carry, t * kChainSegRunDwords + lane, acc, 0, kChainSegRunDwords - 1, nullptr, t);
+  window_emit(win, carry, t * kChainSegRunDwords + lane, acc, 0, kChainSegRunDwords - 1, false, 0u, t);
   window_flush(win, carry, 0);
 }
 

@@ -79,13 +79,14 @@ __device__ __forceinline__ BitmapWindow bitmap_window(uint32_t* bitmap32, const 
 
 // one dword of the chunk-wide bitmap: 'mask' = the bits this lane owns, 'val' its values there
 // (val & ~mask == 0).  combine: 0 store, 1 AND into, 2 OR into.
-// 'old': the dword's present value when the caller has fetched it ahead (window_operand), else NULL.
+// have_old / old: the dword's present value when the caller has fetched it ahead (window_operand).
+// (by value: a pointer to the caller's register made the compiler keep it in scratch)
 __device__ __forceinline__ void window_put(uint32_t* p, uint32_t val, uint32_t mask, int combine, uint32_t coherent,
-                                           const uint32_t* old = nullptr) {
+                                           bool have_old = false, uint32_t old = 0u) {
   if (mask == 0u) return;
   if (mask == ~0u) {
-    if (combine == 1) val &= old ? *old : *p;
-    else if (combine == 2) val |= old ? *old : *p;
+    if (combine == 1) val &= have_old ? old : *p;
+    else if (combine == 2) val |= have_old ? old : *p;
     window_store(p, val, coherent);
     return;
   }
@@ -141,7 +142,8 @@ __device__ __forceinline__ uint32_t window_operand(const BitmapWindow& w, int64_
 
 // run >= 0: the run's index among the page's runs of (last_lane + 1) dwords = its edge slot (runs of 64: derived from d).
 __device__ __forceinline__ void window_emit(const BitmapWindow& w, WindowCarry& cy, int64_t d, uint32_t bm, int combine,
-                                            int last_lane = kWave - 1, const uint32_t* old = nullptr, int64_t run = -1) {
+                                            int last_lane = kWave - 1, bool have_old = false, uint32_t old = 0u,
+                                            int64_t run = -1) {
   const int lane = (int)(threadIdx.x & (kWave - 1));
   const int64_t valid = w.n_rows - d * 32;
   const uint32_t vm = lane > last_lane ? 0u : valid >= 32 ? ~0u : valid <= 0 ? 0u : ((1u << valid) - 1u);
@@ -179,7 +181,7 @@ __device__ __forceinline__ void window_emit(const BitmapWindow& w, WindowCarry& 
   }
   const bool tail = w.own_tail && d == w.tail_dword && mask != 0u;  // zeros behind the chunk's last row
   if (tail) mask |= w.tail_mask;
-  window_put(w.base + d, val, mask, combine, w.coherent, w.shift == 0u ? old : nullptr);
+  window_put(w.base + d, val, mask, combine, w.coherent, have_old && w.shift == 0u, old);
   if (tail && w.tail_extra && combine != 2) window_store(w.base + d + 1, 0u, w.coherent);
 }
 

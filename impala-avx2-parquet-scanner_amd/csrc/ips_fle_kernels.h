@@ -668,7 +668,8 @@ __device__ __forceinline__ void fle_pred_body(const uint64_t* __restrict__ enc, 
   // pages and merged with masked atomics (window_put).  Against the edge-slot version (kept for the fused
   // scans, whose batches are sub-tiles, and the early-pruning w = 32 predicate): Q6 over pages cut differently
   // per column, three launches, 417-429 -> 388 us (the w = 12 BETWEEN launch 171 -> 155 us, three fix-up
-  // launches of 5-14 us gone).
+  // launches of 5-14 us gone) -> 367 us with the AND-into operand fetched ahead (w = 6: 116 -> 102 us, w = 4:
+  // 105 -> 92).
   if constexpr (PAGED) {
     if (win->shift != 0u && win->edges == nullptr) {  // wave-uniform
       constexpr int kRun = 62;
@@ -686,12 +687,26 @@ __device__ __forceinline__ void fle_pred_body(const uint64_t* __restrict__ enc, 
 #pragma unroll
         for (int i = 0; i < L; ++i) rr[i] = buffer_load16<true>(rsrc, (uint32_t)(i * kWave + lane) * 16u);
       };
+      // the dword an AND-into / OR-into launch combines with, fetched with the stripe's planes (fetched where it is
+      // used it put a memory round trip at the end of every stripe: the narrow AND-into launches of a plan)
+      auto operand = [&](int64_t st) -> uint32_t {
+        const int64_t d = st * kRun + lane, first = d * 32 - (int64_t)s;
+        return (args.combine != 0 && lane < kRun && first < n_rows) ? win->base[d] : 0u;
+      };
       u32x4 rr[L];
-      if (t < stripes) load_stripe(t, rr);
+      uint32_t old = 0u;
+      if (t < stripes) {
+        old = operand(t);
+        load_stripe(t, rr);
+      }
       while (t < stripes) {
         tile_to_lds<L>(lds32, W, lane, rr);
         const int64_t next = t + n_waves;
-        if (next < stripes) load_stripe(next, rr);
+        const uint32_t old_now = old;
+        if (next < stripes) {
+          old = operand(next);
+          load_stripe(next, rr);
+        }
         wave_lds_fence();
         const uint32_t rows = bitrev32(evaluate());  // bit j <-> row 32 lane + j of the sub-tile
         uint32_t out;
@@ -713,7 +728,7 @@ __device__ __forceinline__ void fle_pred_body(const uint64_t* __restrict__ enc, 
           const uint32_t val = out & mask;  // (rows behind the page's last one evaluate to anything)
           const bool tail = win->own_tail && d == win->tail_dword && mask != 0u;  // zeros behind the chunk's last row
           if (tail) mask |= win->tail_mask;
-          window_put(win->base + d, val, mask, args.combine, 0u);
+          window_put(win->base + d, val, mask, args.combine, 0u, args.combine != 0, old_now);
           if (tail && win->tail_extra && args.combine != 2) window_store(win->base + d + 1, 0u, 0u);
         }
         wave_lds_fence();
@@ -750,7 +765,7 @@ __device__ __forceinline__ void fle_pred_body(const uint64_t* __restrict__ enc, 
     uint32_t bm = finish_bitmap_dword(sel, tile, lane, n_rows);
     const int64_t d = tile * 64 + lane;
     if constexpr (PAGED) {
-      window_emit(*win, carry, d, bm, args.combine, kWave - 1, window_has_operand(*win, args.combine) ? &old_now : nullptr);
+      window_emit(*win, carry, d, bm, args.combine, kWave - 1, window_has_operand(*win, args.combine), old_now);
     } else if (d < bm_dwords) {
       if (args.combine == 1) bm &= old_now;
       else if (args.combine == 2) bm |= old_now;
@@ -1529,7 +1544,7 @@ __device__ __forceinline__ void fle_pred32_early_body(const uint64_t* __restrict
     uint32_t bm = finish_bitmap_dword(sel, tile, lane, n_rows);
     const int64_t d = tile * 64 + lane;
     if constexpr (PAGED) {
-      window_emit(*win, carry, d, bm, args.combine, kWave - 1, window_has_operand(*win, args.combine) ? &old_now : nullptr);
+      window_emit(*win, carry, d, bm, args.combine, kWave - 1, window_has_operand(*win, args.combine), old_now);
     } else if (d < bm_dwords) {
       if (args.combine == 1) bm &= old_now;
       else if (args.combine == 2) bm |= old_now;

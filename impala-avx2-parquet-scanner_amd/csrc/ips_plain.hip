@@ -316,7 +316,7 @@ __device__ __forceinline__ void plain_tile_body(const S* __restrict__ page, int6
       (void)bm;
     } else if constexpr (PAGED) {
       if (G::R == 32) {
-        window_emit(*win, carry, d, bm, lit.combine, kWave - 1, window_has_operand(*win, lit.combine) ? &old_now : nullptr);
+        window_emit(*win, carry, d, bm, lit.combine, kWave - 1, window_has_operand(*win, lit.combine), old_now);
       } else {  // dword k of the tile sits in lane 2k: bring it to lane k, 32 dwords per tile
         const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_bpermute((2 * lane) << 2, (int)bm);
         window_emit(*win, carry, tile * 32 + lane, mine, lit.combine, 31);

